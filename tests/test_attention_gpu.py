@@ -1,0 +1,126 @@
+"""GPU parity: HIP flash attention (through the C ABI) vs the CPU oracle."""
+import math
+
+import pytest
+import torch
+
+from oracle import attention as oattn
+
+pytestmark = pytest.mark.gpu
+
+# tolerance for bf16 tensors vs the fp32-accumulated oracle: rtol 1.6e-2, atol 1e-2
+RTOL, ATOL = 1.6e-2, 1e-2
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def _run_case(gpu, B, Hq, Hkv, Sq, Sk, D, kv_len=None, layout="bhsd", scale=None, seed=0):
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, Hq, Sq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, Hkv, Sk, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, Sk, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(B, Hq, Sq, D, generator=g).to(torch.bfloat16)
+    kvl = None if kv_len is None else torch.tensor(kv_len, dtype=torch.int32)
+
+    # oracle (fp32 math on the bf16 operands, autograd on CPU)
+    q32, k32, v32 = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = oattn.sdpa(q32, k32, v32, scale=scale, kv_len=kvl, attention_dtype=torch.float32)
+    ref.backward(do.float())
+
+    def put(t):
+        t = t.to(gpu)
+        if layout == "bshd":  # (B,S,H,D) memory viewed as (B,H,S,D)
+            t = t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+        return t.requires_grad_(True)
+
+    qg, kg, vg = put(q), put(k), put(v)
+    out = kernels.flash_attention(qg, kg, vg, kv_len=None if kvl is None else kvl.to(gpu), scale=scale)
+    out.backward(do.to(gpu))
+    torch.cuda.synchronize()
+
+    res = {
+        "out": (out.detach().cpu(), ref.detach()),
+        "dq": (qg.grad.cpu(), q32.grad),
+        "dk": (kg.grad.cpu(), k32.grad),
+        "dv": (vg.grad.cpu(), v32.grad),
+    }
+    for name, (got, want) in res.items():
+        assert got.shape == want.shape, name
+        assert torch.isfinite(got.float()).all(), f"{name} has non-finite values"
+        rel = _rel(got, want)
+        assert rel < 1.2e-2, f"{name}: relative L2 error {rel:.3e}"
+        torch.testing.assert_close(got.float(), want.float(), rtol=RTOL, atol=ATOL * max(1.0, want.abs().max().item()))
+
+
+@pytest.mark.parametrize(
+    "B,Hq,Hkv,Sq,Sk,D",
+    [
+        (2, 10, 10, 1024, 1024, 64),   # SDXL self-attention, 32x32 latent level
+        (1, 20, 20, 256, 77, 64),      # SDXL cross-attention (77 text tokens)
+        (1, 5, 5, 333, 333, 64),       # ragged, not a tile multiple
+        (1, 12, 12, 1160, 1160, 256),  # AuraFlow head_dim 256 (264 text + 896 patches)
+        (1, 4, 4, 520, 520, 128),
+        (1, 24, 8, 640, 640, 96),      # Lumina2 GQA 24q/8kv x 96
+        (1, 2, 2, 1, 1, 64),           # single token
+        (1, 1, 1, 130, 65, 256),
+    ],
+)
+def test_attention_parity(gpu, B, Hq, Hkv, Sq, Sk, D):
+    _run_case(gpu, B, Hq, Hkv, Sq, Sk, D)
+
+
+def test_attention_bshd_layout(gpu):
+    _run_case(gpu, 2, 10, 10, 512, 512, 64, layout="bshd")
+
+
+def test_attention_kv_len_mask(gpu):
+    # Lumina2 prefix key-padding mask (lumina2/denoiser.py:150-155) as kv_len
+    _run_case(gpu, 3, 24, 8, 400, 400, 96, kv_len=[400, 333, 64], scale=math.sqrt(1 / 96))
+    _run_case(gpu, 2, 4, 4, 200, 200, 64, kv_len=[1, 129])
+
+
+def test_attention_large_logits_rescale(gpu):
+    """Force the online-softmax rescale path: one key dominates late in the sequence."""
+    from vision_ft_amd import kernels
+
+    B, H, S, D = 1, 2, 512, 64
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, H, S, D, generator=g)
+    k = torch.randn(B, H, S, D, generator=g)
+    v = torch.randn(B, H, S, D, generator=g)
+    k[:, :, 400] = q[:, :, 7] * 4.0  # spike in the 7th tile for query 7
+    k[:, :, 130] = q[:, :, 300] * 3.0
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    ref = oattn.sdpa(q.float(), k.float(), v.float(), attention_dtype=torch.float32)
+    out = kernels.flash_attention(q.to(gpu), k.to(gpu), v.to(gpu)).cpu()
+    torch.testing.assert_close(out.float(), ref, rtol=RTOL, atol=2e-2)
+
+
+def test_attention_rejects_cpu_and_bad_dim(gpu):
+    from vision_ft_amd import kernels
+
+    q = torch.randn(1, 1, 8, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        kernels.flash_attention(q, q, q)
+    bad = torch.randn(1, 1, 8, 80, dtype=torch.bfloat16, device=gpu)
+    with pytest.raises(ValueError):
+        kernels.flash_attention(bad, bad, bad)
+
+
+def test_attention_deterministic(gpu):
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(5)
+    q, k, v, do = (torch.randn(1, 4, 700, 64, generator=g).to(torch.bfloat16).to(gpu) for _ in range(4))
+    outs = []
+    for _ in range(2):
+        qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = kernels.flash_attention(qq, kk, vv)
+        o.backward(do)
+        outs.append((o.detach(), qq.grad, kk.grad, vv.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -1,0 +1,73 @@
+"""ctypes binding of libvft_hip.so (the C ABI declared in include/vft_hip.h).
+
+The library is built in-tree by ``vision_ft_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no fallback: if the shared object is missing, ``lib()`` raises, and every op in
+``vision_ft_amd.kernels`` raises with it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvft_hip.so")
+
+_lib: ctypes.CDLL | None = None
+
+
+class VftError(RuntimeError):
+    """A C-ABI entry point returned non-zero."""
+
+
+_I64P = POINTER(c_int64)
+_I32P = POINTER(c_int32)
+
+# name -> (restype, argtypes); kept in the order of include/vft_hip.h
+SIGNATURES: dict[str, tuple] = {
+    "vft_version": (c_int, []),
+    "vft_last_error": (c_char_p, []),
+    "vft_device_info": (c_int, [c_int, c_char_p, c_int]),
+    "vft_attn_fwd": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_int] * 6
+        + [_I64P] * 4
+        + [c_float, c_void_p],
+    ),
+    "vft_attn_bwd": (
+        c_int,
+        [c_void_p] * 11 + [c_int] * 6 + [_I64P] * 8 + [c_float, c_void_p],
+    ),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C vision_ft_amd/csrc`). "
+                "vision_ft_amd has no CPU fallback."
+            )
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = cdll
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().vft_last_error().decode("utf-8", "replace")
+        if status == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise VftError(f"{what}: {msg}")
+
+
+def i64x3(values) -> ctypes.Array:
+    return (c_int64 * 3)(*[int(v) for v in values])

@@ -1,0 +1,667 @@
+// Flash attention forward + backward for gfx950 (CDNA4), bf16 in/out, fp32 softmax/accumulate.
+//
+// Replaces the third-party kernels the reference dispatches to from
+//   src/modules/attention.py:98-159 (scaled_dot_product_attention: F.sdpa / flash_attn_func / xformers)
+//   src/modules/attention.py:31-95  (scaled_qkv_attention, AuraFlow entry)
+// Non-causal, dropout 0, optional key-padding mask given as kv_len[b] (Lumina2's prefix bool mask,
+// src/models/lumina2/denoiser.py:150-155), GQA by head-index division (Hq % Hkv == 0).
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16 everywhere):
+//   * every product is arranged so the softmax row (the query) sits on the MFMA *lane* and the
+//     reduction index sits in the accumulator *registers*:  S^T = K·Q^T  (keys in regs, q on lane).
+//     Row max / row sum are then 16 in-lane ops + one lane^32 exchange, and the fp32 accumulator
+//     tile is, after a pairwise bf16 pack, directly the B operand of the next product
+//     (O^T = V^T·P^T, dQ^T = K^T·dS^T, dV^T = dO^T·P, dK^T = Q^T·dS) — P/dS never touch LDS.
+//   * the A operand of those second products is a *column* read of a row-major LDS tile, done with
+//     ds_read_b64_tr_b16 (hardware transpose), so K/V/Q/dO tiles are staged once, row-major.
+//   * LDS rows are padded by 16 B: row stride (D+8)*2 B == 4*odd dwords, conflict-free for
+//     ds_read_b128 fragment reads of 16 consecutive rows.
+//   * global->LDS staging goes through registers and is issued one tile ahead of the compute
+//     (issue loads early, write to LDS after the barrier).
+//
+// Backward is two kernels (no atomics, bitwise reproducible): dkdv (one workgroup per 128 keys,
+// loops over query tiles) and dq (one workgroup per 128 queries, loops over key tiles). Both
+// recompute P from the saved log-sum-exp.
+#include "vft_common.h"
+
+namespace {
+
+struct Str3 {
+    int64_t b, h, s;  // element strides of batch, head, sequence; head_dim is contiguous
+};
+
+struct AttnParams {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* o;              // fwd: out; bwd: forward output (for delta)
+    const bf16_t* dout;     // bwd only
+    bf16_t* dq;
+    bf16_t* dk;
+    bf16_t* dv;
+    float* lse;             // [B, Hq, Sq] natural-log LSE of scaled scores
+    float* delta;           // [B, Hq, Sq] rowsum(dO*O)
+    const int32_t* kv_len;  // [B] or nullptr
+    int B, Hq, Hkv, Sq, Sk;
+    float scale;
+    Str3 sq, sk, sv, so, sdo, sdq, sdk, sdv;
+};
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// Transposed A-operand fragment for a 32(out rows = tile columns) x 16(k = tile rows) block of a
+// row-major [rows][ld] bf16 LDS tile.  The k order inside the step matches the packed-accumulator
+// B operand: element j of lane half h is tile row  row0 + 8*(j>>2) + 4*h + (j&3).
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0, int col0, int lane) {
+    const int h = lane >> 5;
+    const int i = lane & 15;
+    const bf16_t* a0 = tile + (row0 + 4 * h + (i >> 2)) * ld + col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * ld));
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// pack accumulator registers 8*s .. 8*s+7 to the bf16 B-operand fragment of k-step s
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s + j];
+    return r;
+}
+
+// register-staged copy of a ROWS x D bf16 tile into a padded LDS tile, 256 threads
+template <int D, int ROWS>
+struct TileStage {
+    static constexpr int CPR = D / 8;               // 16-byte chunks per row
+    static constexpr int NCH = ROWS * CPR / 256;    // chunks per thread
+    static_assert(ROWS * CPR % 256 == 0, "tile must split evenly over 256 threads");
+    u32x4 r[NCH];
+
+    __device__ __forceinline__ void load(const bf16_t* base, int64_t row_stride, int row0, int row_limit) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 256 + threadIdx.x;
+            const int row = c / CPR, col = (c % CPR) * 8;
+            const int gr = row0 + row;
+            if (gr < row_limit) {
+                r[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)gr * row_stride + col);
+            } else {
+                r[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* lds) const {
+        constexpr int LD = D + 8;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 256 + threadIdx.x;
+            const int row = c / CPR, col = (c % CPR) * 8;
+            *reinterpret_cast<u32x4*>(lds + row * LD + col) = r[i];
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 ldg_frag(const bf16_t* p, bool ok) {
+    if (ok) return *reinterpret_cast<const bf16x8*>(p);
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+    return z;
+}
+
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (bf16_t)a;
+    v[1] = (bf16_t)b;
+    v[2] = (bf16_t)c;
+    v[3] = (bf16_t)d;
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+// =============================================================================================
+// forward: one workgroup = 128 queries (4 waves x 32), key tiles of 64
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    constexpr int LD = D + 8, KS = D / 16, DT = D / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + 64 * LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * 128;
+    const int hkv = hq / (p.Hq / p.Hkv);
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* Ob = p.o + b * p.so.b + hq * p.so.h;
+
+    const int qrow = q0 + w * 32 + r;
+    const bool qok = qrow < p.Sq;
+    bf16x8 Qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+    const float sc = p.scale * kLog2e;
+
+    const int ntiles = (kvl + 63) / 64;
+    TileStage<D, 64> kst, vst;
+    if (ntiles > 0) {
+        kst.load(Kb, p.sk.s, 0, kvl);
+        vst.load(Vb, p.sv.s, 0, kvl);
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        kst.store(Ks);
+        vst.store(Vs);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            kst.load(Kb, p.sk.s, (t + 1) * 64, kvl);
+            vst.load(Vb, p.sv.s, (t + 1) * 64, kvl);
+        }
+
+        // S^T[key][q] = K Q^T
+        f32x16 S[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[kt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * LD + ks * 16 + 8 * h);
+                S[kt] = mfma32(a, Qf[ks], S[kt]);
+            }
+        }
+        const int n0 = t * 64;
+        if (n0 + 64 > kvl) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = n0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= kvl) S[kt][i] = -INFINITY;
+                }
+        }
+        float tmax = S[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, S[kt][i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax * sc);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(S[kt][i] * sc - m_new);
+                psum += pv;
+                S[kt][i] = pv;
+            }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+
+        bf16x8 Pf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) Pf[kk] = pack8(S[kk >> 1], kk & 1);
+
+        // O^T[d][q] += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a = tr_frag(Vs, LD, kk * 16, dt * 32, lane);
+                O[dt] = mfma32(a, Pf[kk], O[dt]);
+            }
+    }
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (qok) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t* dst = Ob + (int64_t)qrow * p.so.s + dt * 32 + 8 * g + 4 * h;
+                store4(dst, O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+            }
+        if (h == 0 && p.lse) {
+            p.lse[((int64_t)b * p.Hq + hq) * p.Sq + qrow] = ltot > 0.f ? (m + __log2f(ltot)) * kLn2 : -INFINITY;
+        }
+    }
+}
+
+// =============================================================================================
+// delta[b,h,q] = sum_d O*dO   (one wave per row)
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nrows = (int64_t)p.B * p.Hq * p.Sq;
+    if (row >= nrows) return;
+    const int q = (int)(row % p.Sq);
+    const int hq = (int)((row / p.Sq) % p.Hq);
+    const int b = (int)(row / ((int64_t)p.Sq * p.Hq));
+    const bf16_t* o = p.o + b * p.so.b + hq * p.so.h + (int64_t)q * p.so.s;
+    const bf16_t* d = p.dout + b * p.sdo.b + hq * p.sdo.h + (int64_t)q * p.sdo.s;
+    float acc = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        bf16x4 a = *reinterpret_cast<const bf16x4*>(o + c);
+        bf16x4 g = *reinterpret_cast<const bf16x4*>(d + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += (float)a[j] * (float)g[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) p.delta[row] = acc;
+}
+
+// =============================================================================================
+// backward dQ: one workgroup = 128 queries, key tiles of 64
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    constexpr int LD = D + 8, KS = D / 16, DT = D / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + 64 * LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * 128;
+    const int hkv = hq / (p.Hq / p.Hkv);
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+    const bf16_t* dOb = p.dout + b * p.sdo.b + hq * p.sdo.h;
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dQb = p.dq + b * p.sdq.b + hq * p.sdq.h;
+
+    const int qrow = q0 + w * 32 + r;
+    const bool qok = qrow < p.Sq;
+    bf16x8 Qf[KS], dOf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+        dOf[ks] = ldg_frag(dOb + (int64_t)qrow * p.sdo.s + ks * 16 + 8 * h, qok);
+    }
+    const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq + qrow;
+    const float lse2 = qok ? p.lse[srow] * kLog2e : INFINITY;
+    const float dl = qok ? p.delta[srow] : 0.f;
+    const float sc = p.scale * kLog2e;
+
+    f32x16 dQ[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+
+    const int ntiles = (kvl + 63) / 64;
+    TileStage<D, 64> kst, vst;
+    if (ntiles > 0) {
+        kst.load(Kb, p.sk.s, 0, kvl);
+        vst.load(Vb, p.sv.s, 0, kvl);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        kst.store(Ks);
+        vst.store(Vs);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            kst.load(Kb, p.sk.s, (t + 1) * 64, kvl);
+            vst.load(Vb, p.sv.s, (t + 1) * 64, kvl);
+        }
+        const int n0 = t * 64;
+        bf16x8 dSf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 S, dP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[i] = 0.f;
+                dP[i] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * LD + ks * 16 + 8 * h);
+                S = mfma32(a, Qf[ks], S);
+                bf16x8 c = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + r) * LD + ks * 16 + 8 * h);
+                dP = mfma32(c, dOf[ks], dP);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = n0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float pv = __builtin_amdgcn_exp2f(S[i] * sc - lse2);
+                if (key >= kvl) pv = 0.f;
+                S[i] = pv * (dP[i] - dl);
+            }
+            dSf[kt * 2] = pack8(S, 0);
+            dSf[kt * 2 + 1] = pack8(S, 1);
+        }
+        // dQ^T[d][q] += K^T dS^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a = tr_frag(Ks, LD, kk * 16, dt * 32, lane);
+                dQ[dt] = mfma32(a, dSf[kk], dQ[dt]);
+            }
+    }
+    if (qok) {
+        const float s = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t* dst = dQb + (int64_t)qrow * p.sdq.s + dt * 32 + 8 * g + 4 * h;
+                store4(dst, dQ[dt][4 * g] * s, dQ[dt][4 * g + 1] * s, dQ[dt][4 * g + 2] * s, dQ[dt][4 * g + 3] * s);
+            }
+    }
+}
+
+// =============================================================================================
+// backward dK/dV: one workgroup = 128 keys (4 waves x 32 keys), query tiles of BQ rows,
+// loops over the query heads that share this kv head
+// =============================================================================================
+template <int D, int BQ>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+    constexpr int LD = D + 8, KS = D / 16, DT = D / 32, QT = BQ / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* dOs = Qs + BQ * LD;
+    float* lse_s = reinterpret_cast<float*>(dOs + BQ * LD);
+    float* dl_s = lse_s + BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hkv = blockIdx.y, n0 = blockIdx.x * 128;
+    const int G = p.Hq / p.Hkv;
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dKb = p.dk + b * p.sdk.b + hkv * p.sdk.h;
+    bf16_t* dVb = p.dv + b * p.sdv.b + hkv * p.sdv.h;
+
+    const int key = n0 + w * 32 + r;
+    const bool kmem = key < p.Sk;   // memory-valid
+    const bool kval = key < kvl;    // participates in the softmax
+
+    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
+        Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
+    }
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dK[dt][i] = 0.f;
+            dV[dt][i] = 0.f;
+        }
+    const float sc = p.scale * kLog2e;
+
+    const int nqt = (p.Sq + BQ - 1) / BQ;
+    const int niter = (n0 < kvl) ? G * nqt : 0;   // fully masked key blocks get zero gradients
+    TileStage<D, BQ> qst, dost;
+    float lse_r = INFINITY, dl_r = 0.f;
+    auto prefetch = [&](int it) {
+        const int g = it / nqt, t = it % nqt;
+        const int hq = hkv * G + g;
+        const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+        const bf16_t* dOb = p.dout + b * p.sdo.b + hq * p.sdo.h;
+        qst.load(Qb, p.sq.s, t * BQ, p.Sq);
+        dost.load(dOb, p.sdo.s, t * BQ, p.Sq);
+        if (tid < BQ) {
+            const int q = t * BQ + tid;
+            const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq + q;
+            lse_r = q < p.Sq ? p.lse[srow] * kLog2e : INFINITY;
+            dl_r = q < p.Sq ? p.delta[srow] : 0.f;
+        }
+    };
+    if (niter > 0) prefetch(0);
+
+    for (int it = 0; it < niter; ++it) {
+        __syncthreads();
+        qst.store(Qs);
+        dost.store(dOs);
+        if (tid < BQ) {
+            lse_s[tid] = lse_r;
+            dl_s[tid] = dl_r;
+        }
+        __syncthreads();
+        if (it + 1 < niter) prefetch(it + 1);
+
+        bf16x8 Pf[2 * QT], dSf[2 * QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x16 S, dP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[i] = 0.f;
+                dP[i] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + r) * LD + ks * 16 + 8 * h);
+                S = mfma32(a, Kf[ks], S);
+                bf16x8 c = *reinterpret_cast<const bf16x8*>(dOs + (qt * 32 + r) * LD + ks * 16 + 8 * h);
+                dP = mfma32(c, Vf[ks], dP);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i]);
+                    if (!kval) pv = 0.f;
+                    S[4 * g4 + i] = pv;
+                    dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                }
+            }
+            Pf[qt * 2] = pack8(S, 0);
+            Pf[qt * 2 + 1] = pack8(S, 1);
+            dSf[qt * 2] = pack8(dP, 0);
+            dSf[qt * 2 + 1] = pack8(dP, 1);
+        }
+        // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2 * QT; ++kk) {
+                bf16x8 a = tr_frag(dOs, LD, kk * 16, dt * 32, lane);
+                dV[dt] = mfma32(a, Pf[kk], dV[dt]);
+                bf16x8 c = tr_frag(Qs, LD, kk * 16, dt * 32, lane);
+                dK[dt] = mfma32(c, dSf[kk], dK[dt]);
+            }
+    }
+    if (kmem) {
+        const float s = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * h;
+                store4(dKb + (int64_t)key * p.sdk.s + d, dK[dt][4 * g] * s, dK[dt][4 * g + 1] * s,
+                       dK[dt][4 * g + 2] * s, dK[dt][4 * g + 3] * s);
+                store4(dVb + (int64_t)key * p.sdv.s + d, dV[dt][4 * g], dV[dt][4 * g + 1], dV[dt][4 * g + 2],
+                       dV[dt][4 * g + 3]);
+            }
+    }
+}
+
+int check_strides(const char* name, const int64_t* s) {
+    for (int i = 0; i < 3; ++i) {
+        if (s[i] < 0 || (s[i] % 8) != 0) {
+            vft_set_error("vft_attn: %s stride[%d]=%lld must be a non-negative multiple of 8 elements", name, i,
+                          (long long)s[i]);
+            return 1;
+        }
+    }
+    return 0;
+}
+int check_ptr(const char* name, const void* p) {
+    if (p == nullptr) {
+        vft_set_error("vft_attn: %s is null", name);
+        return 1;
+    }
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) {
+        vft_set_error("vft_attn: %s must be 16-byte aligned", name);
+        return 1;
+    }
+    return 0;
+}
+Str3 mk(const int64_t* s) { return Str3{s[0], s[1], s[2]}; }
+
+int check_dims(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
+    VFT_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Sq > 0 && Sk > 0, "vft_attn: non-positive dimension");
+    VFT_CHECK_ARG(Hq % Hkv == 0, "vft_attn: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
+    VFT_CHECK_ARG(D == 64 || D == 96 || D == 128 || D == 256, "vft_attn: head_dim %d unsupported (64, 96, 128, 256)", D);
+    VFT_CHECK_ARG(B <= 65535 && Hq <= 65535, "vft_attn: batch/heads exceed grid limits");
+    return 0;
+}
+
+template <int D>
+int launch_fwd(const AttnParams& p, hipStream_t st) {
+    constexpr size_t lds = 2 * 64 * (D + 8) * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr = true;
+    }
+    dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+    hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), lds, st, p);
+    VFT_CHECK_LAUNCH("vft_attn_fwd");
+    return 0;
+}
+
+template <int D, int BQ>
+int launch_bwd(const AttnParams& p, hipStream_t st) {
+    {
+        const int64_t nrows = (int64_t)p.B * p.Hq * p.Sq;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, p, D);
+        VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
+    }
+    {
+        constexpr size_t lds = 2 * BQ * (D + 8) * sizeof(bf16_t) + 2 * BQ * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<D, BQ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        dim3 grid((p.Sk + 127) / 128, p.Hkv, p.B);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, BQ>), grid, dim3(256), lds, st, p);
+        VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
+    }
+    {
+        constexpr size_t lds = 2 * 64 * (D + 8) * sizeof(bf16_t);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);
+        VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, const int32_t* kv_len,
+                            int B, int Hq, int Hkv, int Sq, int Sk, int D, const int64_t* q_strides,
+                            const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, float scale,
+                            void* stream) {
+    if (check_dims(B, Hq, Hkv, Sq, Sk, D)) return 1;
+    if (check_ptr("q", q) || check_ptr("k", k) || check_ptr("v", v) || check_ptr("out", out)) return 1;
+    if (check_strides("q", q_strides) || check_strides("k", k_strides) || check_strides("v", v_strides) ||
+        check_strides("out", o_strides))
+        return 1;
+    AttnParams p{};
+    p.q = (const bf16_t*)q;
+    p.k = (const bf16_t*)k;
+    p.v = (const bf16_t*)v;
+    p.o = (bf16_t*)out;
+    p.lse = lse;
+    p.kv_len = kv_len;
+    p.B = B, p.Hq = Hq, p.Hkv = Hkv, p.Sq = Sq, p.Sk = Sk;
+    p.scale = scale;
+    p.sq = mk(q_strides), p.sk = mk(k_strides), p.sv = mk(v_strides), p.so = mk(o_strides);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 64: return launch_fwd<64>(p, st);
+        case 96: return launch_fwd<96>(p, st);
+        case 128: return launch_fwd<128>(p, st);
+        default: return launch_fwd<256>(p, st);
+    }
+}
+
+extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                            const float* lse, void* dq, void* dk, void* dv, float* delta_ws, const int32_t* kv_len,
+                            int B, int Hq, int Hkv, int Sq, int Sk, int D, const int64_t* q_strides,
+                            const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                            const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                            const int64_t* dv_strides, float scale, void* stream) {
+    if (check_dims(B, Hq, Hkv, Sq, Sk, D)) return 1;
+    if (check_ptr("q", q) || check_ptr("k", k) || check_ptr("v", v) || check_ptr("out", out) ||
+        check_ptr("dout", dout) || check_ptr("dq", dq) || check_ptr("dk", dk) || check_ptr("dv", dv))
+        return 1;
+    VFT_CHECK_ARG(lse != nullptr && delta_ws != nullptr, "vft_attn_bwd: lse / delta workspace is null");
+    if (check_strides("q", q_strides) || check_strides("k", k_strides) || check_strides("v", v_strides) ||
+        check_strides("out", o_strides) || check_strides("dout", do_strides) || check_strides("dq", dq_strides) ||
+        check_strides("dk", dk_strides) || check_strides("dv", dv_strides))
+        return 1;
+    AttnParams p{};
+    p.q = (const bf16_t*)q;
+    p.k = (const bf16_t*)k;
+    p.v = (const bf16_t*)v;
+    p.o = (bf16_t*)const_cast<void*>(out);
+    p.dout = (const bf16_t*)dout;
+    p.dq = (bf16_t*)dq;
+    p.dk = (bf16_t*)dk;
+    p.dv = (bf16_t*)dv;
+    p.lse = const_cast<float*>(lse);
+    p.delta = delta_ws;
+    p.kv_len = kv_len;
+    p.B = B, p.Hq = Hq, p.Hkv = Hkv, p.Sq = Sq, p.Sk = Sk;
+    p.scale = scale;
+    p.sq = mk(q_strides), p.sk = mk(k_strides), p.sv = mk(v_strides), p.so = mk(o_strides);
+    p.sdo = mk(do_strides), p.sdq = mk(dq_strides), p.sdk = mk(dk_strides), p.sdv = mk(dv_strides);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 64: return launch_bwd<64, 64>(p, st);
+        case 96: return launch_bwd<96, 64>(p, st);
+        case 128: return launch_bwd<128, 64>(p, st);
+        default: return launch_bwd<256, 32>(p, st);
+    }
+}

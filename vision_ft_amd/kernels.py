@@ -1,0 +1,121 @@
+"""torch.autograd.Function wrappers over the C ABI (include/vft_hip.h).
+
+PyTorch is used here for device memory, streams and autograd bookkeeping only; every op below
+runs a hand-written HIP kernel from libvft_hip.so on ``torch.cuda.current_stream()``.
+There is no CPU path: tensors that are not on a CUDA(HIP) device raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _C
+
+
+def _ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(*tensors: torch.Tensor, dtype: torch.dtype | None = torch.bfloat16) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "vision_ft_amd kernels run on MI355X only: got a tensor on "
+                f"{t.device}. There is no CPU fallback (use oracle/ in tests for CPU checks)."
+            )
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError(f"expected {dtype}, got {t.dtype}")
+
+
+def _bhsd_ok(t: torch.Tensor) -> bool:
+    return t.stride(-1) == 1 and all(s % 8 == 0 for s in t.stride()[:3]) and t.data_ptr() % 16 == 0
+
+
+def _as_bhsd(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` (B,H,S,D) with head_dim contiguous and 8-element-aligned strides (copy if needed)."""
+    if _bhsd_ok(t):
+        return t
+    b, h, s, d = t.shape
+    return t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+
+
+def _empty_bshd_as_bhsd(b: int, h: int, s: int, d: int, like: torch.Tensor) -> torch.Tensor:
+    # memory (B,S,H,D), logical (B,H,S,D): the transformer blocks re-flatten heads right after
+    # attention, which is then a free view
+    return torch.empty((b, s, h, d), dtype=like.dtype, device=like.device).permute(0, 2, 1, 3)
+
+
+class _FlashAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kv_len, scale):
+        _require_gpu(q, k, v)
+        q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+        B, Hq, Sq, D = q.shape
+        _, Hkv, Sk, _ = k.shape
+        if v.shape != k.shape or k.shape[0] != B or k.shape[3] != D:
+            raise ValueError(f"attention shape mismatch: q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+        if kv_len is not None:
+            _require_gpu(kv_len, dtype=torch.int32)
+            if kv_len.shape != (B,):
+                raise ValueError("kv_len must be int32 of shape (B,)")
+            kv_len = kv_len.contiguous()
+        out = _empty_bshd_as_bhsd(B, Hq, Sq, D, q)
+        lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            st = _C.lib().vft_attn_fwd(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(kv_len),
+                B, Hq, Hkv, Sq, Sk, D,
+                _C.i64x3(q.stride()[:3]), _C.i64x3(k.stride()[:3]), _C.i64x3(v.stride()[:3]),
+                _C.i64x3(out.stride()[:3]), float(scale), _stream(),
+            )
+        _C.check(st, "vft_attn_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, kv_len)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, kv_len = ctx.saved_tensors
+        B, Hq, Sq, D = q.shape
+        _, Hkv, Sk, _ = k.shape
+        dout = _as_bhsd(dout.to(torch.bfloat16))
+        dq = _empty_bshd_as_bhsd(B, Hq, Sq, D, q)
+        dk = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
+        dv = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
+        delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            st = _C.lib().vft_attn_bwd(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
+                _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), _ptr(kv_len),
+                B, Hq, Hkv, Sq, Sk, D,
+                _C.i64x3(q.stride()[:3]), _C.i64x3(k.stride()[:3]), _C.i64x3(v.stride()[:3]),
+                _C.i64x3(out.stride()[:3]), _C.i64x3(dout.stride()[:3]), _C.i64x3(dq.stride()[:3]),
+                _C.i64x3(dk.stride()[:3]), _C.i64x3(dv.stride()[:3]), ctx.scale, _stream(),
+            )
+        _C.check(st, "vft_attn_bwd")
+        return dq, dk, dv, None, None
+
+
+def flash_attention(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    kv_len: torch.Tensor | None = None,
+    scale: float | None = None,
+) -> torch.Tensor:
+    """softmax(scale * q k^T) v over (B,H,S,D) bf16 tensors; `kv_len` (B,) int32 masks keys >= kv_len[b].
+
+    Kv heads may be fewer than query heads (GQA). The result is logically (B,Hq,Sq,D) with
+    (B,Sq,Hq,D) memory order.
+    """
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    return _FlashAttention.apply(q, k, v, kv_len, scale)
