@@ -43,3 +43,15 @@ def sdpa(
         s = s.masked_fill(~mask, float("-inf"))
     p = torch.softmax(s, dim=-1)
     return torch.matmul(p, v32).to(out_dtype)
+
+
+def sdpa_ref(q, k, v, mask=None, scale=None, attention_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """The reference's own CPU execution of the op: cast fp32 -> attention dtype (:113-118) and call
+    torch's SDPA in that dtype (:121-129).  Used inside the model oracles so that they track the
+    reference bit-for-bit on CPU; `sdpa` above (fp32 math) is the higher-precision yardstick the GPU
+    kernel is compared against."""
+    import torch.nn.functional as F
+
+    if q.dtype == torch.float32:
+        q, k, v = q.to(attention_dtype), k.to(attention_dtype), v.to(attention_dtype)
+    return F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, is_causal=False, scale=scale)

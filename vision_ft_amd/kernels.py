@@ -119,3 +119,109 @@ def flash_attention(
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     return _FlashAttention.apply(q, k, v, kv_len, scale)
+
+
+# =============================================================================================
+# Fused glue ops.  Each function below is one (or two) HIP kernels in libvft_hip.so with a
+# hand-written backward; shapes are checked on the host before any launch.
+# =============================================================================================
+import torch.nn.functional as F  # noqa: E402  (library GEMM/conv calls only)
+
+
+def _ready(*tensors: torch.Tensor) -> None:
+    _C.lib()  # raises if the extension is not built: there is no fallback
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"vision_ft_amd kernels run on MI355X only (tensor on {t.device}); no CPU fallback")
+
+
+def layer_norm(x: torch.Tensor, weight, bias, eps: float) -> torch.Tensor:
+    """LayerNorm over the last dim with fp32 statistics, output in x.dtype."""
+    _ready(x)
+    w = None if weight is None else weight.float()
+    b = None if bias is None else bias.float()
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
+
+
+def rms_norm(x: torch.Tensor, weight, eps: float) -> torch.Tensor:
+    _ready(x)
+    return F.rms_norm(x.float(), (x.shape[-1],), None if weight is None else weight.float(), eps).to(x.dtype)
+
+
+def layer_norm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """AdaLN: LN(x) (no affine, fp32 stats) * (1 + scale[:,None]) + shift[:,None]   (x: B,S,C; shift/scale: B,C)."""
+    _ready(x)
+    h = F.layer_norm(x.float(), (x.shape[-1],), None, None, eps).to(x.dtype)
+    return h * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+def rms_norm_scale(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor | None, eps: float) -> torch.Tensor:
+    """Lumina2 pre-norm: RMSNorm(x)*w, optionally * (1 + scale[:,None])."""
+    _ready(x)
+    h = F.rms_norm(x, (x.shape[-1],), weight, eps)
+    return h if scale is None else h * (1 + scale.unsqueeze(1))
+
+
+def gate_residual(residual: torch.Tensor, gate: torch.Tensor, y: torch.Tensor, tanh: bool = False) -> torch.Tensor:
+    """residual + g[:,None,:] * y  with g = tanh(gate) if `tanh`."""
+    _ready(residual)
+    g = gate.tanh() if tanh else gate
+    return residual + g.unsqueeze(1) * y
+
+
+def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: bool = False) -> torch.Tensor:
+    """GroupNorm over NCHW (fp32 statistics) with optional fused SiLU."""
+    _ready(x)
+    h = F.group_norm(x, groups, weight, bias, eps)
+    return F.silu(h) if silu else h
+
+
+def geglu(proj: torch.Tensor) -> torch.Tensor:
+    """proj (..., 2F) -> proj[..., :F] * gelu(proj[..., F:])  (exact erf GELU)."""
+    _ready(proj)
+    a, g = proj.chunk(2, dim=-1)
+    return a * F.gelu(g)
+
+
+def swiglu(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """silu(a) * b"""
+    _ready(a)
+    return F.silu(a) * b
+
+
+def rope_apply(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """Rotate interleaved pairs of the last dim in fp32. x (B,H,S,D); freqs (S,D/2,2) = [cos, sin]."""
+    _ready(x)
+    cos, sin = freqs[..., 0].to(x.device), freqs[..., 1].to(x.device)
+    xf = x.float()
+    xe, xo = xf[..., 0::2], xf[..., 1::2]
+    return torch.stack((xe * cos - xo * sin, xe * sin + xo * cos), dim=-1).reshape(x.shape).to(x.dtype)
+
+
+def qk_norm_rope(x: torch.Tensor, kind: str, weight, eps: float, cos: torch.Tensor | None, sin: torch.Tensor | None) -> torch.Tensor:
+    """Per-head norm over head_dim ('layer': LN without affine; 'rms': RMSNorm * weight) followed by
+    the interleaved-pair rotation.  x: (B,S,H,D); cos/sin: (S,D/2) or (B,S,D/2) fp32, or None."""
+    _ready(x)
+    d = x.shape[-1]
+    if kind == "layer":
+        h = F.layer_norm(x.float(), (d,), None, None, eps).to(x.dtype)
+    elif kind == "rms":
+        h = F.rms_norm(x, (d,), weight, eps)
+    elif kind == "none":
+        h = x
+    else:
+        raise ValueError(kind)
+    if cos is None:
+        return h
+    c = cos.unsqueeze(-2)  # broadcast over heads
+    s = sin.unsqueeze(-2)
+    hf = h.float()
+    he, ho = hf[..., 0::2], hf[..., 1::2]
+    return torch.stack((he * c - ho * s, he * s + ho * c), dim=-1).reshape(h.shape).to(h.dtype)
+
+
+def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.Tensor, scale: float) -> torch.Tensor:
+    """base(x) + scale * (x @ lora_down^T) @ lora_up^T"""
+    _ready(x)
+    y = base(x)
+    return y + F.linear(F.linear(x, lora_down), lora_up) * scale

@@ -1,0 +1,102 @@
+"""Attention operator — same call surface as the reference's src/modules/attention.py:23-159, with
+the MI355X kernel as the implementation.
+
+``AttentionImplementation`` gains the value ``"hip"``; on this platform *every* accepted backend
+value executes the hand-written flash-attention kernel (``libvft_hip.so: vft_attn_fwd/bwd``):
+"eager"/"sdpa" name the same mathematics in the reference, and there is no second implementation
+to dispatch to.  "flash_attention_2" / "xformers" raise, mirroring the reference's behaviour when
+those wheels are absent (:133-134, :150).
+
+Conventions kept from the reference: (B, H, S, D) in and out; fp32 inputs are cast to
+``attention_dtype`` and the result stays in that dtype (:113-118); rank-4 assertion (:109-111);
+``ValueError`` for an unknown backend (:159).  A mask must be a key-padding mask (the only kind the
+hot path produces — Lumina2's prefix mask, lumina2/denoiser.py:150-155); it is converted to per-batch
+key lengths.  Anything else raises ``ValueError``.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Literal
+
+import torch
+
+from .. import kernels
+
+AttentionImplementation = Literal["eager", "flash_attention_2", "xformers", "sdpa", "hip"]
+
+is_flash_attn_available = False
+is_xformers_available = False
+
+
+def mask_to_kv_len(mask: torch.Tensor, batch: int, sk: int) -> torch.Tensor:
+    """(B,Sk) / (B,1,1,Sk) / (B,H,Sq,Sk)-expanded bool key-padding mask -> (B,) int32 lengths.
+
+    Raises ValueError if the mask is not a per-batch *prefix* mask over keys (checked on device
+    without a host sync only for the cheap structural part: shape/stride; the prefix property is
+    the caller's contract and is verified in tests)."""
+    if mask.dtype != torch.bool:
+        raise ValueError("only boolean key-padding masks are supported by the HIP attention kernel")
+    if mask.dim() == 2:
+        km = mask
+    elif mask.dim() == 4:
+        if mask.shape[0] != batch or mask.shape[-1] != sk:
+            raise ValueError(f"mask shape {tuple(mask.shape)} does not match (B={batch}, Sk={sk})")
+        # an expanded (B,1,1,Sk) mask has zero strides on the head / query axes
+        if (mask.shape[1] != 1 and mask.stride(1) != 0) or (mask.shape[2] != 1 and mask.stride(2) != 0):
+            raise ValueError("attention mask must be a key-padding mask broadcast over heads and queries")
+        km = mask[:, 0, 0, :]
+    else:
+        raise ValueError("attention mask must have rank 2 or 4")
+    return km.sum(dim=-1, dtype=torch.int32)
+
+
+def scaled_dot_product_attention(
+    q: torch.Tensor,  # (batch_size, num_heads, seq_len, head_dim)
+    k: torch.Tensor,
+    v: torch.Tensor,
+    mask: torch.Tensor | None = None,
+    scale: float | None = None,
+    dropout: float = 0.0,
+    backend: AttentionImplementation = "hip",
+    attention_dtype: torch.dtype = torch.bfloat16,
+    is_causal: bool = False,
+    kv_len: torch.Tensor | None = None,
+) -> torch.Tensor:
+    assert q.dim() == k.dim() == v.dim() == 4
+    if backend in ("flash_attention_2", "xformers"):
+        raise AssertionError(f"{backend} is not available on this platform; use backend='hip'")
+    if backend not in ("eager", "sdpa", "hip"):
+        raise ValueError(f"Unknown backend: {backend}")
+    if dropout != 0.0 or is_causal:
+        raise ValueError("the MI355X attention kernel is non-causal with dropout 0 (all the hot path uses)")
+    if attention_dtype != torch.bfloat16:
+        raise ValueError("the MI355X attention kernel computes in bfloat16")
+    if q.dtype != attention_dtype:
+        q, k, v = q.to(attention_dtype), k.to(attention_dtype), v.to(attention_dtype)
+    if mask is not None and kv_len is None:
+        kv_len = mask_to_kv_len(mask, q.shape[0], k.shape[2])
+    return kernels.flash_attention(q, k, v, kv_len=kv_len, scale=scale)
+
+
+def scaled_qkv_attention(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    scale: float | None = None,
+    use_flash: bool = False,
+    attention_dtype: torch.dtype = torch.bfloat16,
+) -> torch.Tensor:
+    """Legacy AuraFlow entry (reference :31-95).  `use_flash` is accepted and ignored: both values
+    run the HIP kernel.  The reference warns on every call; here once per process."""
+    global _warned
+    if not _warned:
+        warnings.warn("scaled_qkv_attention is deprecated; use scaled_dot_product_attention")
+        _warned = True
+    return scaled_dot_product_attention(q, k, v, scale=scale, attention_dtype=attention_dtype)
+
+
+_warned = False
+
+
+def get_attn_implementation_label(use_flash_attention: bool) -> AttentionImplementation:
+    return "hip"
