@@ -45,6 +45,22 @@ def sdpa(
     return torch.matmul(p, v32).to(out_dtype)
 
 
+_TRUTH = False
+
+
+class fp32_truth:
+    """Context manager: make `sdpa_ref` keep everything in fp32 (no bf16 cast).  Used by tests to
+    obtain a high-precision yardstick from the same restatement (run WITHOUT autocast)."""
+
+    def __enter__(self):
+        global _TRUTH
+        self._old, _TRUTH = _TRUTH, True
+
+    def __exit__(self, *exc):
+        global _TRUTH
+        _TRUTH = self._old
+
+
 def sdpa_ref(q, k, v, mask=None, scale=None, attention_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
     """The reference's own CPU execution of the op: cast fp32 -> attention dtype (:113-118) and call
     torch's SDPA in that dtype (:121-129).  Used inside the model oracles so that they track the
@@ -52,6 +68,8 @@ def sdpa_ref(q, k, v, mask=None, scale=None, attention_dtype: torch.dtype = torc
     kernel is compared against."""
     import torch.nn.functional as F
 
+    if _TRUTH:
+        return F.scaled_dot_product_attention(q.float(), k.float(), v.float(), attn_mask=mask, scale=scale)
     if q.dtype == torch.float32:
         q, k, v = q.to(attention_dtype), k.to(attention_dtype), v.to(attention_dtype)
     return F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, is_causal=False, scale=scale)

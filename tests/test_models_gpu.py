@@ -28,12 +28,29 @@ def _to_gpu_module(mod_cls, cfg, P, gpu):
     return m.to(device=gpu, dtype=torch.bfloat16)
 
 
-def _check_grads(model, T, oracle_grads):
+def _check_grads(model, oracle_bf16: dict, truth_fp32: dict):
+    """Parameter gradients: the GPU result must be as close to the fp32 truth as the reference's own
+    bf16-autocast numerics are (x2 slack), or within 3e-2 — deep, tiny gradients carry several % of
+    bf16 noise on *both* sides, so comparing two bf16 runs to each other directly is meaningless."""
     named = dict(model.named_parameters())
-    for name, want in oracle_grads.items():
+    for name, truth in truth_fp32.items():
         got = named[name].grad
         assert got is not None, name
-        assert rel_err(got.cpu(), want) < 3e-2, (name, rel_err(got.cpu(), want))
+        e_gpu = rel_err(got.cpu(), truth)
+        e_ref = rel_err(oracle_bf16[name], truth)
+        assert e_gpu < max(3e-2, 2.0 * e_ref), (name, e_gpu, e_ref)
+
+
+def _truth_grads(forward_loss, P, grad_names, x):
+    """fp32 run of the oracle (no autocast, fp32 attention) -> grads of `grad_names` and of x."""
+    from oracle.attention import fp32_truth
+
+    Pt = {k: (v.clone().requires_grad_(True) if k in grad_names else v) for k, v in P.items()}
+    xt = x.clone().requires_grad_(True)
+    with fp32_truth():
+        loss = forward_loss(Pt, xt)
+    loss.backward()
+    return {n: Pt[n].grad for n in grad_names}, xt.grad, loss.detach()
 
 
 def _lora_train_gpu(model, include, forward_loss, lora_keys, steps=3):
@@ -100,8 +117,12 @@ def test_sdxl_denoiser_parity(gpu):
     assert rel_err(out.cpu(), out_o) < TENSOR_TOL, rel_err(out.cpu(), out_o)
     assert rel_err(out.cpu(), T["out"]) < TENSOR_TOL  # and vs the reference's own output
     torch.testing.assert_close(loss.cpu().float(), loss_o.float(), rtol=LOSS_RTOL, atol=0)
-    assert rel_err(x.grad.cpu(), x_o.grad) < 3e-2
-    _check_grads(model, T, {n: Po[n].grad for n in grad_names})
+    tg, tx, tl = _truth_grads(
+        lambda P_, x_: ops.ddpm_loss(T["noise"], osdxl.unet_forward(P_, cfg, x_, T["timestep"], T["ehs"], T["pooled"],
+                                                                      T["original_size"], T["target_size"], T["crop"])),
+        Pb, grad_names, T["noisy"])
+    assert rel_err(x.grad.cpu(), tx) < max(3e-2, 2 * rel_err(x_o.grad, tx))
+    _check_grads(model, {n: Po[n].grad for n in grad_names}, tg)
 
     losses = _lora_train_gpu(
         model, ["attn1", "attn2", ".ff."],
@@ -139,8 +160,11 @@ def test_auraflow_denoiser_parity(gpu, tag):
     assert rel_err(out.cpu(), out_o) < TENSOR_TOL, rel_err(out.cpu(), out_o)
     assert rel_err(out.cpu(), T["out"]) < TENSOR_TOL
     torch.testing.assert_close(loss.cpu().float(), loss_o.float(), rtol=LOSS_RTOL, atol=0)
-    assert rel_err(x.grad.cpu(), x_o.grad) < 3e-2
-    _check_grads(model, T, {n: Po[n].grad for n in grad_names})
+    tg, tx, tl = _truth_grads(
+        lambda P_, x_: ops.flow_loss(T["latents"], T["noise"], oaura.mmdit_forward(P_, cfg, x_, T["ehs"], T["timestep"])),
+        Pb, grad_names, T["noisy"])
+    assert rel_err(x.grad.cpu(), tx) < max(3e-2, 2 * rel_err(x_o.grad, tx))
+    _check_grads(model, {n: Po[n].grad for n in grad_names}, tg)
 
     losses = _lora_train_gpu(
         model, [".attn.", ".mlp"],
@@ -185,8 +209,12 @@ def test_lumina2_denoiser_parity(gpu):
     assert rel_err(out.cpu(), out_o) < TENSOR_TOL, rel_err(out.cpu(), out_o)
     assert rel_err(out.cpu(), T["out"]) < TENSOR_TOL
     torch.testing.assert_close(loss.cpu().float(), loss_o.float(), rtol=LOSS_RTOL, atol=0)
-    assert rel_err(x.grad.cpu(), x_o.grad) < 3e-2
-    _check_grads(model, T, {n: Po[n].grad for n in grad_names})
+    tg, tx, tl = _truth_grads(
+        lambda P_, x_: ops.flow_loss(T["latents"], T["noise"], -torch.stack(
+            olum.nextdit_forward(P_, cfg, x_, T["caption"], T["timestep"], T["caption_mask"])[0], 0)),
+        Pb, grad_names, T["noisy"])
+    assert rel_err(x.grad.cpu(), tx) < max(3e-2, 2 * rel_err(x_o.grad, tx))
+    _check_grads(model, {n: Po[n].grad for n in grad_names}, tg)
 
     # ragged batch: two resolutions in one call
     with torch.no_grad():
@@ -194,7 +222,9 @@ def test_lumina2_denoiser_parity(gpu):
                             caption_features=g["caption"], caption_mask=g["caption_mask"])
     r0, r1 = o2.unbind()
     assert rel_err(r0.cpu(), T["ragged.out0"]) < TENSOR_TOL and rel_err(r1.cpu(), T["ragged.out1"]) < TENSOR_TOL
-    assert rel_err(capf.cpu(), T["ragged.caption_features"]) < TENSOR_TOL
+    # refined caption features: only the valid (unpadded) rows are ever consumed downstream
+    for i, n in enumerate(T["caption_mask"].sum(-1).tolist()):
+        assert rel_err(capf[i, :n].cpu(), T["ragged.caption_features"][i, :n]) < TENSOR_TOL
 
     losses = _lora_train_gpu(
         model, ["attention", "feed_forward"],

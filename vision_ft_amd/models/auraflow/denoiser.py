@@ -23,6 +23,7 @@ import torch.utils.checkpoint as checkpoint
 from ... import kernels
 from ...modules.attention import scaled_dot_product_attention
 from ...modules.positional_encoding.rope import RoPEFrequency
+from ...utils.tensor import module_dtype
 from .config import DenoiserConfig
 
 DENOISER_TENSOR_PREFIX = "model."
@@ -233,7 +234,7 @@ class TimestepEmbedder(nn.Module):
 
     def forward(self, timestep: torch.Tensor) -> torch.Tensor:
         freq = self.timestep_embedding(timestep.float(), self.frequency_embedding_size)
-        return self.mlp(freq.to(self.mlp[0].weight.dtype))
+        return self.mlp(freq.to(module_dtype(self.mlp[0])))
 
 
 class MMDiT(nn.Module):
@@ -340,7 +341,7 @@ class MMDiT(nn.Module):
     def forward(self, latent: torch.Tensor, encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
                 shortcut_duration: int | None = None, guidance_scale: float | None = None, **kwargs) -> torch.Tensor:
         b, _c, height, width = latent.shape
-        dtype = self.init_x_linear.weight.dtype
+        dtype = module_dtype(self.init_x_linear)
         cond = self.cond_seq_linear(encoder_hidden_states[:b].to(dtype))
         cond = torch.cat([self.register_tokens.expand(b, -1, -1).to(dtype), cond], dim=1)
 

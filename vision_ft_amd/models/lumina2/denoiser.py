@@ -29,6 +29,7 @@ from ... import kernels
 from ...modules.attention import scaled_dot_product_attention
 from ...modules.norm import FP32LayerNorm
 from ...modules.timestep.embedding import get_timestep_embedding
+from ...utils.tensor import module_dtype
 from .config import DenoiserConfig
 
 DENOISER_TENSOR_PREFIX = "model.diffusion_model."
@@ -51,7 +52,7 @@ class TimestepEmbedder(nn.Module):
 
     def forward(self, timesteps: torch.Tensor) -> torch.Tensor:
         emb = get_timestep_embedding(timesteps, self.time_embed_dim, flip_sin_to_cos=True, downscale_freq_shift=0)
-        return self.mlp(emb.to(self.mlp[0].weight.dtype))
+        return self.mlp(emb.to(module_dtype(self.mlp[0])))
 
 
 class Rope(NamedTuple):
@@ -307,7 +308,7 @@ class NextDiT(nn.Module):
 
     def forward(self, latents, caption_features, timestep: torch.Tensor, caption_mask, cached_caption_features=None):
         dev = timestep.device
-        dtype = self.x_embedder.weight.dtype
+        dtype = module_dtype(self.x_embedder)
         images = list(latents.unbind()) if isinstance(latents, torch.Tensor) else list(latents)
         b = len(images)
         p = self.patch_size

@@ -23,6 +23,7 @@ import torch.utils.checkpoint as checkpoint
 from ... import kernels
 from ...modules.attention import AttentionImplementation, scaled_dot_product_attention
 from ...modules.timestep.embedding import get_timestep_embedding
+from ...utils.tensor import module_dtype
 from .config import DOWN_BLOCK_NAME, MID_BLOCK_NAME, UP_BLOCK_NAME, DenoiserConfig
 
 
@@ -474,7 +475,7 @@ class UNet(nn.Module):
     def forward(self, latents: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 encoder_pooler_output: torch.Tensor, original_size: torch.Tensor, target_size: torch.Tensor,
                 crop_coords_top_left: torch.Tensor, cross_attention_kwargs: dict | None = None) -> torch.Tensor:
-        dtype = self.out[2].weight.dtype
+        dtype = module_dtype(self.out[2])
         latents = latents.to(dtype)
         context = encoder_hidden_states.to(dtype)
         t_emb, g_emb = self.prepare_global_condition(timestep, encoder_pooler_output, original_size, target_size,

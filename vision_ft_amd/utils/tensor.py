@@ -19,3 +19,12 @@ def set_requires_grad(model: nn.Module, requires_grad: bool = True) -> None:
         p.requires_grad = requires_grad
     if hasattr(model, "set_requires_grad"):
         model.set_requires_grad(requires_grad)
+
+
+def module_dtype(module: nn.Module) -> torch.dtype:
+    """Compute dtype of a (possibly adapter-wrapped or quantised) layer: dtype of its first
+    floating-point parameter."""
+    for p in module.parameters():
+        if p.is_floating_point():
+            return p.dtype
+    return torch.bfloat16
