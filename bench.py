@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — training images/sec of the denoiser step on synthetic bucketed latents (MI355X).
+
+  python bench.py --gpus N --steps K --warmup W [--workload sdxl_lora|sdxl_full|aura_lora|lumina_lora] [--batch B]
+
+For N>1 launch one rank per GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from
+the environment); gradients are exchanged with RCCL on a side stream (vision_ft_amd/trainer/dp.py).
+One "step" = noising + denoiser forward + loss + backward + gradient exchange + AdamW update on one
+batch of B synthetic latents per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic train TFLOP per image at 1024^2 (recompute not counted)
+F_ALG = {"sdxl_lora": 13.5, "sdxl_full": 20.3, "aura_lora": 88.0, "lumina_lora": 47.6}
+
+
+def build(workload: str, device: torch.device):
+    from vision_ft_amd.modules.peft import LoRAConfig, PeftTargetConfig, RegexMatch
+
+    torch.manual_seed(42)
+    with torch.device(device):
+        if workload.startswith("sdxl"):
+            from vision_ft_amd.models.sdxl import Denoiser, DenoiserConfig
+
+            model = Denoiser(DenoiserConfig())
+            peft = PeftTargetConfig(include_keys=["attn1", "attn2", ".ff."], config=LoRAConfig(rank=4, alpha=1.0))
+        elif workload.startswith("aura"):
+            from vision_ft_amd.models.auraflow import Denoiser, DenoiserConfig
+
+            model = Denoiser(DenoiserConfig())
+            # tests/assets/debug_dataset.yml:17-25 key set of the reference (252 Linears, rank 16)
+            peft = PeftTargetConfig(
+                include_keys=[RegexMatch(regex=r".*\.attn\.w2[qkvo]"), RegexMatch(regex=r".*\.mlp[X]?\."),
+                              RegexMatch(regex=r".*single_layers\.\d+\.attn\.w1[qkvo]")],
+                exclude_keys=["text_encoder", "vae", "t_embedder", "final_linear", RegexMatch(regex=r"\.mod[CX]{1,2}")],
+                config=LoRAConfig(rank=16, alpha=1.0))
+            with torch.no_grad():  # the reference zero-inits these; re-init so outputs are non-trivial
+                for n, p in model.named_parameters():
+                    if ".mod" in n or n in ("final_linear.weight", "cond_seq_linear.weight"):
+                        p.normal_(0, 0.02)
+        else:
+            from vision_ft_amd.models.lumina2 import Denoiser, DenoiserConfig
+
+            model = Denoiser(DenoiserConfig())
+            peft = PeftTargetConfig(include_keys=["attention", "feed_forward"],
+                                    exclude_keys=["text_encoder", "vae", "noise_refiner"], config=LoRAConfig(rank=4, alpha=1.0))
+    model = model.to(torch.bfloat16)
+    if workload.endswith("_lora"):
+        model.requires_grad_(False)
+        peft.replace_to_peft_layer(model)
+    model.train()
+    return model
+
+
+def make_step(workload: str, model, device, batch: int, seed: int):
+    from vision_ft_amd.modules.loss import diffusion as LD
+    from vision_ft_amd.modules.loss import flow_match as LF
+    from vision_ft_amd.modules.timestep.sampling import sigmoid_randn, uniform_rand, uniform_randint
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)  # noqa: E731
+    if workload.startswith("sdxl"):
+        lat, ctx, pooled = rn(batch, 4, 128, 128), rn(batch, 77, 2048), rn(batch, 1280)
+        size = torch.tensor([[1024, 1024]] * batch, device=device)
+        crop = torch.zeros(batch, 2, dtype=torch.long, device=device)
+
+        def fwd():
+            t = uniform_randint(lat.shape, device)
+            noisy, noise = LD.prepare_noised_latents(lat, t)
+            pred = model(latents=noisy, timestep=t, encoder_hidden_states=ctx, encoder_pooler_output=pooled,
+                         original_size=size, target_size=size, crop_coords_top_left=crop)
+            return LD.loss_with_predicted_noise(lat, noise, pred.float())
+    elif workload.startswith("aura"):
+        lat, ctx = rn(batch, 4, 128, 128), rn(batch, 256, 2048)
+
+        def fwd():
+            t = sigmoid_randn(lat.shape, device)
+            noisy, noise = LF.prepare_noised_latents(lat, t.to(lat.dtype))
+            pred = model(latent=noisy, encoder_hidden_states=ctx, timestep=t)
+            return LF.loss_with_predicted_velocity(lat.float(), noise.float(), pred.float())
+    else:
+        lat, cap = rn(batch, 16, 128, 128), rn(batch, 256, 2304)
+        mask = torch.ones(batch, 256, dtype=torch.bool, device=device)
+
+        def fwd():
+            t = uniform_rand(lat.shape, device)
+            noisy, noise = LF.prepare_noised_latents(lat, (1 - t).to(lat.dtype))
+            out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask)
+            pred = -torch.nested.to_padded_tensor(out, padding=0.0)
+            return LF.loss_with_predicted_velocity(lat.float(), noise.float(), pred.float())
+    return fwd
+
+
+def cpu_baseline(threads: int) -> dict:
+    from oracle.bench_cpu import time_sdxl_lora_step
+    from vision_ft_amd.models.sdxl import Denoiser, DenoiserConfig
+    from vision_ft_amd.utils.state_dict import get_target_keys
+
+    with torch.device("meta"):
+        m = Denoiser(DenoiserConfig())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    linears = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.Linear)]
+    targets = sorted(set(get_target_keys(["attn1", "attn2", ".ff."], [], [n for n, _ in m.named_modules()])) & set(linears))
+    r = time_sdxl_lora_step(shapes, targets, threads=threads, warmup=1, steps=2)
+    return {"value": round(r["images_per_s"], 5), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle restatement of BASELINE config 1 (SDXL UNet LoRA r4 x{len(targets)} Linears, B=1, 512^2, AdamW, "
+                      f"autocast cpu bf16): 1 warm-up + 2 timed steps, {r['s_per_step']:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sdxl_lora", choices=list(F_ALG))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from vision_ft_amd import kernels
+    from vision_ft_amd.trainer.dp import DataParallelGrads
+
+    batch = args.batch or {"sdxl_lora": 4, "sdxl_full": 4, "aura_lora": 2, "lumina_lora": 2}[args.workload]
+    model = build(args.workload, device)
+    params = [p for p in model.parameters() if p.requires_grad]
+    dp = DataParallelGrads(params)
+    opt = torch.optim.AdamW(params, lr=1e-3, fused=True)
+    fwd = make_step(args.workload, model, device, batch, seed=42 + rank)
+
+    def step():
+        loss = fwd()
+        loss.backward()
+        dp.reduce_async()
+        dp.wait()
+        opt.step()
+        dp.zero_grad()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernels.set_profiling(rank == 0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = kernels.profile_report() if rank == 0 else {}
+    kernels.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images_s = world * batch * args.steps / elapsed
+        # roofline of the dominant hand-written kernel (attention forward): ALGORITHMIC flops / measured time
+        fwd_keys = [k for k in prof if k.startswith("attn_fwd")]
+        work = sum(prof[k]["work"] for k in fwd_keys)
+        ms = sum(prof[k]["ms"] for k in fwd_keys)
+        ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": sum(prof[k]["launches"] for k in fwd_keys) // max(args.steps, 1),
+                    "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+                    "step_mfma_frac": round(images_s / world * F_ALG[args.workload] / PEAK_BF16_MFMA_TFLOPS, 4)}
+        out = {
+            "metric": "train images/sec at 1024^2", "value": round(images_s, 3), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": args.workload, "resolution": "1024x1024", "per_gpu_batch": batch,
+                       "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)",
+                       "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss), 5)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(threads=min(os.cpu_count() or 1, 16))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

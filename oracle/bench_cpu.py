@@ -1,0 +1,66 @@
+"""CPU baseline leg of bench.py: times the oracle's restatement of BASELINE config 1 (SDXL UNet,
+LoRA rank 4 on ["attn1","attn2",".ff."], batch 1, 512x512 -> latents 1x4x64x64, AdamW lr 1e-3,
+autocast cpu bf16) on the host cores of the box it runs on.  TEST/BENCH INFRASTRUCTURE ONLY — a
+reported baseline, never the product path."""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from . import ops
+from . import sdxl as osdxl
+
+
+def _random_params(shapes: dict[str, tuple], lora_targets: list[str], rank: int) -> dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(42)
+    P: dict[str, torch.Tensor] = {}
+    for name, shape in shapes.items():
+        if len(shape) == 1:
+            t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = (torch.rand(shape, generator=g) * 2 - 1) / fan_in**0.5
+        P[name] = t
+    for n in lora_targets:
+        w = P.pop(f"{n}.weight")
+        P[f"{n}.linear.weight"] = w
+        if f"{n}.bias" in P:
+            P[f"{n}.linear.bias"] = P.pop(f"{n}.bias")
+        P[f"{n}.lora_down.weight"] = ((torch.rand(rank, w.shape[1], generator=g) * 2 - 1) / w.shape[1] ** 0.5).to(torch.bfloat16)
+        P[f"{n}.lora_up.weight"] = torch.zeros(w.shape[0], rank, dtype=torch.bfloat16)
+        P[f"{n}.alpha"] = torch.tensor(1.0, dtype=torch.bfloat16)
+    return P
+
+
+def time_sdxl_lora_step(shapes: dict[str, tuple], lora_targets: list[str], threads: int, warmup: int = 1,
+                        steps: int = 2, rank: int = 4) -> dict:
+    torch.set_num_threads(threads)
+    cfg = osdxl.SDXLCfg()
+    P = _random_params(shapes, lora_targets, rank)
+    params = [v.requires_grad_(True) for k, v in P.items() if ".lora_down." in k or ".lora_up." in k]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    ctx = torch.randn(1, 77, 2048, generator=g)
+    pooled = torch.randn(1, 1280, generator=g)
+    size = torch.tensor([[512, 512]])
+    crop = torch.tensor([[0, 0]])
+    times = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        t = torch.randint(0, 1000, (1,), generator=g, dtype=torch.int32)
+        noise = torch.randn(lat.shape, generator=g)
+        noisy = ops.ddpm_noise(lat, t, noise)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            pred = osdxl.unet_forward(P, cfg, noisy, t, ctx, pooled, size, size, crop)
+            loss = ops.ddpm_loss(noise, pred)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    s = sum(times) / len(times)
+    return {"s_per_step": s, "images_per_s": 1.0 / s, "loss": float(loss)}

@@ -53,6 +53,45 @@ def _empty_bshd_as_bhsd(b: int, h: int, s: int, d: int, like: torch.Tensor) -> t
     return torch.empty((b, s, h, d), dtype=like.dtype, device=like.device).permute(0, 2, 1, 3)
 
 
+# ---------------------------------------------------------------------------------------------
+# optional per-launch timing with HIP events on the launch stream (used by bench.py's roofline leg;
+# events are asynchronous — nothing here synchronises)
+# ---------------------------------------------------------------------------------------------
+_PROFILE: dict[str, list] | None = None
+
+
+def set_profiling(enabled: bool) -> None:
+    global _PROFILE
+    _PROFILE = {} if enabled else None
+
+
+class _Timed:
+    def __init__(self, name: str, work: float):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.t1.record()
+            _PROFILE.setdefault(self.name, []).append((self.work, self.t0, self.t1))
+
+
+def profile_report() -> dict[str, dict]:
+    """{kernel: {"launches", "work" (flops or bytes, summed), "ms" (summed), "avg_ms"}}; call after
+    torch.cuda.synchronize()."""
+    out = {}
+    for name, recs in (_PROFILE or {}).items():
+        ms = sum(a.elapsed_time(b) for _, a, b in recs)
+        out[name] = {"launches": len(recs), "work": sum(w for w, _, _ in recs), "ms": ms, "avg_ms": ms / max(len(recs), 1)}
+    return out
+
+
 class _FlashAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, kv_len, scale):
@@ -69,7 +108,7 @@ class _FlashAttention(torch.autograd.Function):
             kv_len = kv_len.contiguous()
         out = _empty_bshd_as_bhsd(B, Hq, Sq, D, q)
         lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
-        with torch.cuda.device(q.device):
+        with torch.cuda.device(q.device), _Timed(f"attn_fwd_d{D}", 4.0 * B * Hq * Sq * Sk * D):
             st = _C.lib().vft_attn_fwd(
                 _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(kv_len),
                 B, Hq, Hkv, Sq, Sk, D,
@@ -91,7 +130,7 @@ class _FlashAttention(torch.autograd.Function):
         dk = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
         dv = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
         delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
-        with torch.cuda.device(q.device):
+        with torch.cuda.device(q.device), _Timed(f"attn_bwd_d{D}", 10.0 * B * Hq * Sq * Sk * D):
             st = _C.lib().vft_attn_bwd(
                 _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
                 _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), _ptr(kv_len),

@@ -44,4 +44,5 @@ def prepare_noised_latents(
 
 
 def loss_with_predicted_noise(latents: torch.Tensor, random_noise: torch.Tensor, predicted_noise: torch.Tensor) -> torch.Tensor:
-    return F.mse_loss(predicted_noise, random_noise, reduction="mean")
+    # fp32 like the reference under autocast (mse_loss is an autocast-to-fp32 op)
+    return F.mse_loss(predicted_noise.float(), random_noise.float(), reduction="mean")

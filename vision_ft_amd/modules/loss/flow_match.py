@@ -37,7 +37,7 @@ def get_flow_match_target_velocity(latents: torch.Tensor, random_noise: torch.Te
 
 
 def loss_with_predicted_velocity(latents: torch.Tensor, random_noise: torch.Tensor, predicted_velocity: torch.Tensor) -> torch.Tensor:
-    return F.mse_loss(predicted_velocity, random_noise - latents, reduction="mean")
+    return F.mse_loss(predicted_velocity.float(), (random_noise - latents).float(), reduction="mean")
 
 
 ModelPredictionType = Literal["noise", "velocity", "image"]
