@@ -64,6 +64,85 @@ int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides,
                  const int64_t* dk_strides, const int64_t* dv_strides, float scale, void* stream);
 
+/* ---- LoRA -----------------------------------------------------------------------------------
+ * Replace the low-rank branch of LoRALinear.forward, src/modules/peft/lora.py:92-104
+ *   linear(x) + lora_up(lora_down(dropout(x))) * (alpha / rank)
+ * and the skinny GEMMs autograd derives from it.  All tensors bf16, row-major 2-D views (tokens
+ * flattened to M rows); ld* are row strides in elements; lora_down is (r,K), lora_up is (N,r), both
+ * contiguous; r <= 16; K, N multiples of 8.
+ *
+ * vft_lora_fwd:     y[M,N] += scale * (x[M,K] . lora_down^T) . lora_up^T, in place on the base GEMM's
+ *                   output.  Also writes t_out[M,r] = x . lora_down^T and up_t_out[r,N] = lora_up^T
+ *                   (both saved for backward; either may be NULL).
+ * vft_lora_bwd_dx:  dx[M,K] += scale * (dy[M,N] . lora_up) . lora_down, in place on the base dgrad;
+ *                   takes lora_up^T (r,N) from the forward; writes u_out[M,r] = dy . lora_up.
+ * vft_lora_wgrad2:  d_down[r,K] = scale * u^T x ;  d_up[N,r] = scale * dy^T t   (one launch pair,
+ *                   deterministic two-stage reduction; workspace >= vft_lora_wgrad_workspace()).
+ */
+int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora_up, void* t_out,
+                 void* up_t_out, int M, int K, int N, int r, int64_t ldx, int64_t ldy, float scale,
+                 void* stream);
+int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
+                    int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream);
+size_t vft_lora_wgrad_workspace(int M, int K, int N, int r);
+int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t, void* d_down,
+                    void* d_up, float* workspace, size_t ws_bytes, int M, int K, int N, int r,
+                    int64_t ldx, int64_t lddy, float scale, void* stream);
+
+/* ---- row norms -----------------------------------------------------------------------------
+ * LayerNorm / RMSNorm over the last dimension with fp32 statistics, optional per-channel affine
+ * (weight, bias: bf16 [C]) and optional AdaLN modulation y = norm(x)*(1+scale[b]) + shift[b]
+ * (scale/shift: bf16 [rows/rows_per_batch][C]).  kind: 0 = LayerNorm, 1 = RMSNorm.
+ * Replaces nn.LayerNorm (sdxl/denoiser.py:250-252), Fp32LayerNorm + modulate
+ * (auraflow/denoiser.py:59-76), nn.RMSNorm + (1+scale) (lumina2/denoiser.py:280-313),
+ * FP32LayerNorm (modules/norm.py:9-17).  mean/rstd: fp32 [rows], saved for backward.
+ */
+int vft_norm_fwd(const void* x, void* y, const void* weight, const void* bias, const void* scale,
+                 const void* shift, float* mean, float* rstd, int64_t rows, int C, int64_t ldx,
+                 int rows_per_batch, int kind, float eps, void* stream);
+int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const void* scale,
+                    const float* mean, const float* rstd, void* dx, int64_t rows, int C, int64_t ldx,
+                    int rows_per_batch, int kind, void* stream);
+
+/* ---- per-head q/k norm + RoPE ---------------------------------------------------------------
+ * x: (B,S,H,D) bf16 addressed by x_strides[3] = {batch, seq, head} (so views into a fused qkv
+ * projection work), y/dx: (B,S,H,D) contiguous.  kind: 0 LayerNorm without affine (AuraFlow,
+ * auraflow/denoiser.py:165-174), 1 RMSNorm * weight[D] (Lumina2, lumina2/denoiser.py:96-97),
+ * 2 none.  cos/sin: fp32 (S, D/2) [cs_batch_stride = 0] or (B, S, D/2); NULL = no rotation.
+ * Rotation = interleaved pairs (rope.py:83-111) == complex multiply (lumina2/denoiser.py:103-112).
+ */
+int vft_qk_norm_rope_fwd(const void* x, void* y, const void* weight, const float* cos, const float* sin,
+                         float* mean, float* rstd, int B, int S, int H, int D, const int64_t* x_strides,
+                         int64_t cs_batch_stride, int kind, float eps, void* stream);
+int vft_qk_norm_rope_bwd(const void* dy, const void* x, const void* weight, const float* cos,
+                         const float* sin, const float* mean, const float* rstd, void* dx, int B, int S,
+                         int H, int D, const int64_t* x_strides, int64_t cs_batch_stride, int kind,
+                         void* stream);
+
+/* ---- GroupNorm (+SiLU), NCHW ---------------------------------------------------------------
+ * Replaces GroupNorm -> SiLU of the SDXL ResidualBlock (sdxl/denoiser.py:511-551) and the
+ * SpatialTransformer norm (:303).  stats/bstats: fp32 [N*G*2] workspaces; dweight/dbias: optional
+ * fp32 [C] accumulators.  H*W must be a multiple of 8.
+ */
+int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats,
+                      int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
+int vft_groupnorm_bwd(const void* x, const void* dy, const float* stats, const void* weight,
+                      const void* bias, void* dx, float* bstats, float* dweight, float* dbias, int N,
+                      int C, int HW, int G, float eps, int fuse_silu, void* stream);
+
+/* ---- gated activations / gated residual ------------------------------------------------------
+ * GEGLU: out[M,F] = proj[:, :F] * gelu(proj[:, F:])   (sdxl/denoiser.py:183-186, exact erf GELU)
+ * SwiGLU: out = silu(a) * b                            (auraflow/denoiser.py:113-119, lumina2 :212-219)
+ * gate_residual: out = residual + f(gate[b,:]) * y, f = tanh (lumina2 :303,311) or identity
+ *                (auraflow :408-422); residual may be NULL (then out = f(gate)*y, used in backward).
+ */
+int vft_geglu_fwd(const void* proj, void* out, int64_t M, int F, void* stream);
+int vft_geglu_bwd(const void* proj, const void* dy, void* dproj, int64_t M, int F, void* stream);
+int vft_swiglu_fwd(const void* a, const void* b, void* out, int64_t n, void* stream);
+int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void* db, int64_t n, void* stream);
+int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,
+                      int C, int rows_per_batch, int use_tanh, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,157 @@
+"""GPU parity of the fused norm / activation / rope kernels vs plain fp32 PyTorch on CPU
+(tolerance: relative L2 < 8e-3 for bf16 outputs of fp32 math)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops
+
+from .helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 8e-3
+
+
+def _g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def _bf(g, *shape, sc=1.0, off=0.0):
+    return (torch.randn(*shape, generator=g) * sc + off).to(torch.bfloat16)
+
+
+def _run(fn_gpu, fn_ref, inputs, gpu, grad_idx):
+    gin = [t.to(gpu).requires_grad_(i in grad_idx) if t is not None else None for i, t in enumerate(inputs)]
+    rin = [t.float().requires_grad_(i in grad_idx) if t is not None else None for i, t in enumerate(inputs)]
+    yg, yr = fn_gpu(*gin), fn_ref(*rin)
+    gy = torch.randn(yr.shape, generator=_g(99)).to(torch.bfloat16)
+    yg.backward(gy.to(gpu))
+    yr.backward(gy.float())
+    assert yg.shape == yr.shape and yg.dtype == torch.bfloat16
+    assert rel_err(yg.cpu(), yr) < TOL, ("out", rel_err(yg.cpu(), yr))
+    for i in grad_idx:
+        e = rel_err(gin[i].grad.cpu(), rin[i].grad)
+        assert e < 1.2e-2, (i, e)
+
+
+@pytest.mark.parametrize("rows,C", [((2, 77), 640), ((3, 1000), 1280), ((1, 5), 2304), ((2, 33), 5120), ((4,), 64)])
+def test_layer_norm_affine(gpu, rows, C):
+    from vision_ft_amd import kernels
+
+    g = _g(1)
+    x, w, b = _bf(g, *rows, C, sc=2.0, off=0.5), _bf(g, C, sc=0.2, off=1.0), _bf(g, C, sc=0.1)
+    _run(lambda x, w, b: kernels.layer_norm(x, w, b, 1e-5), lambda x, w, b: F.layer_norm(x, (C,), w, b, 1e-5),
+         [x, w, b], gpu, (0, 1, 2))
+
+
+def test_layer_norm_modulate_and_rms_scale(gpu):
+    from vision_ft_amd import kernels
+
+    g = _g(2)
+    B, S, C = 3, 130, 3072
+    x, sh, sc = _bf(g, B, S, C, sc=1.5), _bf(g, B, C, sc=0.3), _bf(g, B, C, sc=0.3)
+    _run(lambda x, sh, sc: kernels.layer_norm_modulate(x, sh, sc, 1e-5),
+         lambda x, sh, sc: F.layer_norm(x, (C,), None, None, 1e-5) * (1 + sc.unsqueeze(1)) + sh.unsqueeze(1),
+         [x, sh, sc], gpu, (0, 1, 2))
+    C = 2304
+    x, w, sc = _bf(g, B, S, C, sc=1.5), _bf(g, C, sc=0.2, off=1.0), _bf(g, B, C, sc=0.3)
+    _run(lambda x, w, sc: kernels.rms_norm_scale(x, w, sc, 1e-5),
+         lambda x, w, sc: F.rms_norm(x, (C,), w, 1e-5) * (1 + sc.unsqueeze(1)), [x, w, sc], gpu, (0, 1, 2))
+    _run(lambda x, w: kernels.rms_norm_scale(x, w, None, 1e-5), lambda x, w: F.rms_norm(x, (C,), w, 1e-5),
+         [x, w], gpu, (0, 1))
+
+
+@pytest.mark.parametrize("N,C,H,W,silu,eps", [(2, 320, 32, 32, True, 1e-5), (3, 640, 16, 24, False, 1e-6),
+                                               (1, 1280, 8, 8, True, 1e-5), (2, 64, 4, 4, True, 1e-5)])
+def test_group_norm_silu(gpu, N, C, H, W, silu, eps):
+    from vision_ft_amd import kernels
+
+    g = _g(3)
+    x, w, b = _bf(g, N, C, H, W, sc=2.0, off=0.3), _bf(g, C, sc=0.2, off=1.0), _bf(g, C, sc=0.1)
+
+    def ref(x, w, b):
+        y = F.group_norm(x, 32, w, b, eps)
+        return F.silu(y) if silu else y
+
+    _run(lambda x, w, b: kernels.group_norm(x, w, b, 32, eps, silu=silu), ref, [x, w, b], gpu, (0, 1, 2))
+
+
+def test_geglu_swiglu_gate_residual(gpu):
+    from vision_ft_amd import kernels
+
+    g = _g(4)
+    p = _bf(g, 2, 300, 2 * 2560, sc=1.5)
+
+    def geglu_ref(p):
+        a, gt = p.chunk(2, dim=-1)
+        return a * F.gelu(gt)
+
+    _run(kernels.geglu, geglu_ref, [p], gpu, (0,))
+    a, b = _bf(g, 2, 111, 8192, sc=1.5), _bf(g, 2, 111, 8192)
+    _run(kernels.swiglu, lambda a, b: F.silu(a) * b, [a, b], gpu, (0, 1))
+    res, gate, y = _bf(g, 3, 50, 3072), _bf(g, 3, 3072, sc=0.5), _bf(g, 3, 50, 3072)
+    for use_tanh in (False, True):
+        _run(lambda r, gt, y: kernels.gate_residual(r, gt, y, tanh=use_tanh),
+             lambda r, gt, y: r + (gt.tanh() if use_tanh else gt).unsqueeze(1) * y, [res, gate, y], gpu, (0, 1, 2))
+
+
+@pytest.mark.parametrize("D,H,kind", [(256, 12, "layer"), (96, 24, "rms"), (96, 8, "rms"), (64, 4, "layer"), (128, 3, "rms")])
+def test_qk_norm_rope(gpu, D, H, kind):
+    from vision_ft_amd import kernels
+
+    g = _g(5)
+    B, S = 2, 77
+    x = _bf(g, B, S, H, D, sc=1.5, off=0.2)
+    w = _bf(g, D, sc=0.2, off=1.0) if kind == "rms" else None
+    ang = torch.rand(B, S, D // 2, generator=g) * 6.28
+    cos, sin = ang.cos(), ang.sin()
+    eps = 1e-6 if kind == "rms" else 1e-5
+
+    def ref(x, w=None):
+        n = F.layer_norm(x, (D,), None, None, eps) if kind == "layer" else F.rms_norm(x, (D,), w, eps)
+        n = n + (n.to(torch.bfloat16).float() - n).detach()  # reference rounds before rotating (straight-through)
+        e, o = n[..., 0::2], n[..., 1::2]
+        c, s = cos.unsqueeze(2), sin.unsqueeze(2)
+        return torch.stack((e * c - o * s, e * s + o * c), dim=-1).reshape(x.shape)
+
+    if kind == "rms":
+        _run(lambda x, w: kernels.qk_norm_rope(x, kind, w, eps, cos.to(gpu), sin.to(gpu)), ref, [x, w], gpu, (0, 1))
+    else:
+        _run(lambda x: kernels.qk_norm_rope(x, kind, None, eps, cos.to(gpu), sin.to(gpu)), ref, [x], gpu, (0,))
+
+
+def test_qk_norm_rope_strided_view_and_shared_table(gpu):
+    """Lumina-style views into a fused qkv projection + an (S, D/2) table shared by the batch."""
+    from vision_ft_amd import kernels
+
+    g = _g(6)
+    B, S, H, D = 2, 40, 6, 96
+    qkv = _bf(g, B, S, (H + 4) * D)
+    ang = torch.rand(S, D // 2, generator=g) * 6.28
+    w = _bf(g, D, sc=0.2, off=1.0)
+    q = qkv[..., : H * D].unflatten(-1, (H, D))
+    out = kernels.qk_norm_rope(q.to(gpu) if False else qkv.to(gpu)[..., : H * D].unflatten(-1, (H, D)), "rms", w.to(gpu), 1e-6,
+                               ang.cos().to(gpu), ang.sin().to(gpu))
+    n = F.rms_norm(q.float(), (D,), w.float(), 1e-6).to(torch.bfloat16).float()
+    e, o = n[..., 0::2], n[..., 1::2]
+    c, s = ang.cos()[None, :, None, :], ang.sin()[None, :, None, :]
+    ref = torch.stack((e * c - o * s, e * s + o * c), dim=-1).reshape(q.shape)
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+def test_rope_apply_matches_reference_golden(gpu):
+    from vision_ft_amd.modules.positional_encoding.rope import applye_rope_frequencies, get_rope_frequencies, image_position_indices
+
+    from .helpers import load_golden
+
+    G = load_golden("ops.safetensors")[0]
+    pos = image_position_indices(16, 24, 3)
+    assert torch.equal(pos, G["rope.pos"])
+    freqs = get_rope_frequencies(torch.cat([torch.zeros(5, 3), pos], 0), [8, 12, 12], 10000)
+    assert torch.equal(freqs, G["rope.freqs"])  # table construction is bit-exact
+    # head_dim 32 of the fixture is below the kernel's minimum: check the rotation on a padded copy
+    x = torch.zeros(2, 3, freqs.shape[0], 64, dtype=torch.bfloat16)
+    x[..., :32] = G["rope.x"].to(torch.bfloat16)
+    f64 = torch.cat([freqs, torch.stack([torch.ones(freqs.shape[0], 16), torch.zeros(freqs.shape[0], 16)], -1)], dim=1)
+    out = applye_rope_frequencies(x.to(gpu), f64)
+    assert rel_err(out[..., :32].cpu(), G["rope.out_bf16"]) < 1e-2

@@ -1,0 +1,204 @@
+// GroupNorm (+ fused SiLU) over NCHW bf16 activations, fp32 statistics — gfx950.
+//
+// Replaces cuDNN/ATen GroupNorm followed by a separate SiLU in the SDXL ResidualBlock
+// (src/models/sdxl/denoiser.py:511-551, GN32 eps 1e-5 -> SiLU -> conv) and the SpatialTransformer
+// input norm (:303, eps 1e-6, no activation).
+//
+// Two HBM passes per direction (statistics, then apply): a group of an NCHW tensor is one contiguous
+// run of (C/G)·H·W elements, so both passes stream with 16-byte accesses.  The statistics pass runs
+// one workgroup per (n, c) plane and folds its two partial sums into the group's accumulator with
+// two fp32 atomics (B·C·2 atomics in total — negligible).  Algorithmic bytes: forward 3·N·2 (two
+// reads + one write of the tensor), backward 5·N·2.
+#include "vft_common.h"
+
+namespace {
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// stats[(n*G+g)*2 + {0,1}] += (Σx, Σx²) of plane (n, c)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int C,
+                                                       int HW, int cpg) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x;  // n*C + c
+    const int n = plane / C, c = plane % C;
+    const bf16_t* xp = x + (int64_t)plane * HW;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x * 8; e < HW; e += 256 * 8) {
+        float v[8];
+        ld8(xp + e, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s1 += v[i];
+            s2 += v[i] * v[i];
+        }
+    }
+    s1 = block_sum<4>(s1, red);
+    s2 = block_sum<4>(s2, red);
+    if (threadIdx.x == 0) {
+        const int G = C / cpg;
+        float* st = stats + ((int64_t)n * G + c / cpg) * 2;
+        atomicAdd(st, s1);
+        atomicAdd(st + 1, s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                       const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ y, int C, int HW, int cpg, float eps,
+                                                       int silu, int64_t nvec) {
+    const int G = C / cpg;
+    const float invL = 1.f / ((float)cpg * (float)HW);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
+        const int64_t idx = e * 8;
+        const int64_t plane = idx / HW;
+        const int c = (int)(plane % C);
+        const int64_t n = plane / C;
+        const float* st = stats + (n * G + c / cpg) * 2;
+        const float mean = st[0] * invL;
+        const float rstd = rsqrtf(fmaxf(st[1] * invL - mean * mean, 0.f) + eps);
+        const float wc = w ? (float)w[c] : 1.f, bc = b ? (float)b[c] : 0.f;
+        const float a = rstd * wc, o = bc - mean * a;
+        float v[8];
+        ld8(x + idx, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float z = v[i] * a + o;
+            v[i] = silu ? silu_f(z) : z;
+        }
+        st8(y + idx, v);
+    }
+}
+
+// bstats[(n*G+g)*2 + {0,1}] += (Σ g, Σ g·xhat), g = dz·w_c, dz = dy·silu'(z) (or dy);
+// optionally dw[c] += Σ dz·xhat, db[c] += Σ dz
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           const float* __restrict__ stats, const bf16_t* __restrict__ w,
+                                                           const bf16_t* __restrict__ b, float* __restrict__ bstats,
+                                                           float* __restrict__ dw, float* __restrict__ db, int C, int HW,
+                                                           int cpg, float eps, int silu) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x;
+    const int n = plane / C, c = plane % C;
+    const int G = C / cpg;
+    const float invL = 1.f / ((float)cpg * (float)HW);
+    const float* st = stats + ((int64_t)n * G + c / cpg) * 2;
+    const float mean = st[0] * invL;
+    const float rstd = rsqrtf(fmaxf(st[1] * invL - mean * mean, 0.f) + eps);
+    const float wc = w ? (float)w[c] : 1.f, bc = b ? (float)b[c] : 0.f;
+    const bf16_t* xp = x + (int64_t)plane * HW;
+    const bf16_t* dp = dy + (int64_t)plane * HW;
+    float sz = 0.f, szx = 0.f;
+    for (int e = threadIdx.x * 8; e < HW; e += 256 * 8) {
+        float v[8], d[8];
+        ld8(xp + e, v);
+        ld8(dp + e, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (v[i] - mean) * rstd;
+            float dz = d[i];
+            if (silu) dz *= dsilu_f(xh * wc + bc);
+            sz += dz;
+            szx += dz * xh;
+        }
+    }
+    sz = block_sum<4>(sz, red);
+    szx = block_sum<4>(szx, red);
+    if (threadIdx.x == 0) {
+        float* bs = bstats + ((int64_t)n * G + c / cpg) * 2;
+        atomicAdd(bs, sz * wc);
+        atomicAdd(bs + 1, szx * wc);
+        if (dw) atomicAdd(dw + c, szx);
+        if (db) atomicAdd(db + c, sz);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                        const float* __restrict__ stats, const float* __restrict__ bstats,
+                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                        bf16_t* __restrict__ dx, int C, int HW, int cpg, float eps,
+                                                        int silu, int64_t nvec) {
+    const int G = C / cpg;
+    const float invL = 1.f / ((float)cpg * (float)HW);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
+        const int64_t idx = e * 8;
+        const int64_t plane = idx / HW;
+        const int c = (int)(plane % C);
+        const int64_t n = plane / C;
+        const int64_t row = n * G + c / cpg;
+        const float mean = stats[row * 2] * invL;
+        const float rstd = rsqrtf(fmaxf(stats[row * 2 + 1] * invL - mean * mean, 0.f) + eps);
+        const float mg = bstats[row * 2] * invL, mgx = bstats[row * 2 + 1] * invL;
+        const float wc = w ? (float)w[c] : 1.f, bc = b ? (float)b[c] : 0.f;
+        float v[8], d[8];
+        ld8(x + idx, v);
+        ld8(dy + idx, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (v[i] - mean) * rstd;
+            float dz = d[i];
+            if (silu) dz *= dsilu_f(xh * wc + bc);
+            v[i] = rstd * (dz * wc - mg - xh * mgx);
+        }
+        st8(dx + idx, v);
+    }
+}
+
+unsigned grid_for(int64_t nvec) {
+    int64_t b = (nvec + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+int gn_args(const char* name, int N, int C, int HW, int G) {
+    VFT_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "%s: bad shape N=%d C=%d HW=%d G=%d", name, N, C, HW, G);
+    VFT_CHECK_ARG(HW % 8 == 0, "%s: H*W=%d must be a multiple of 8", name, HW);
+    return 0;
+}
+
+}  // namespace
+
+// stats: [N*G*2] fp32 workspace, written here (saved for backward)
+extern "C" int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats, int N, int C,
+                                 int HW, int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && y && stats, "vft_groupnorm_fwd: null pointer");
+    if (gn_args("vft_groupnorm_fwd", N, C, HW, G)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(float), st);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, stats, C, HW, C / G);
+    VFT_CHECK_LAUNCH("vft_groupnorm_fwd(stats)");
+    const int64_t nvec = (int64_t)N * C * HW / 8;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, stats,
+                       (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)y, C, HW, C / G, eps, fuse_silu, nvec);
+    VFT_CHECK_LAUNCH("vft_groupnorm_fwd(apply)");
+    return 0;
+}
+
+// bstats: [N*G*2] fp32 scratch; dweight/dbias: optional [C] fp32 accumulators (zeroed here)
+extern "C" int vft_groupnorm_bwd(const void* x, const void* dy, const float* stats, const void* weight, const void* bias,
+                                 void* dx, float* bstats, float* dweight, float* dbias, int N, int C, int HW, int G,
+                                 float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && dy && stats && dx && bstats, "vft_groupnorm_bwd: null pointer");
+    if (gn_args("vft_groupnorm_bwd", N, C, HW, G)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(bstats, 0, (size_t)N * G * 2 * sizeof(float), st);
+    if (dweight) hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
+    if (dbias) hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats,
+                       (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, C, HW, C / G, eps, fuse_silu);
+    VFT_CHECK_LAUNCH("vft_groupnorm_bwd(stats)");
+    const int64_t nvec = (int64_t)N * C * HW / 8;
+    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       stats, bstats, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, C, HW, C / G, eps,
+                       fuse_silu, nvec);
+    VFT_CHECK_LAUNCH("vft_groupnorm_bwd(dx)");
+    return 0;
+}

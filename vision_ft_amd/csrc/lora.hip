@@ -1,0 +1,331 @@
+// Low-rank adapter kernels (LoRA), bf16 in/out, fp32 accumulate — gfx950.
+//
+// Replace the three extra cuBLAS launches + scale + add that the reference's LoRALinear issues per
+// layer (src/modules/peft/lora.py:92-104:  linear(x) + lora_up(lora_down(x)) * (alpha/rank)) and the
+// four skinny GEMMs autograd adds in backward.  Every kernel is an HBM-bound streaming pass over a
+// token-major activation; the rank-sized operands come from L2 / LDS / registers.
+//
+//   vft_lora_fwd     y[M,N] += s · (x[M,K] · Aᵀ) · Bᵀ      one launch: per 16-row block, phase 1 builds
+//                                                           t = x·Aᵀ (MFMA 16x16x32, K split over the 4
+//                                                           waves, reduced through LDS), phase 2 streams
+//                                                           the block's rows of y.  Also emits t (saved
+//                                                           for backward) and Bᵀ (so backward's dy·B is
+//                                                           again a k-contiguous product).
+//   vft_lora_bwd_dx  dx[M,K] += s · (dy[M,N] · B) · A       same structure; emits u = dy·B.
+//   vft_lora_wgrad2  dA = s · uᵀ x,  dB = s · dyᵀ t         both weight gradients in one launch pair
+//                                                           (partials per 256-row block, then a
+//                                                           deterministic reduce).
+//
+// Algorithmic HBM bytes per layer (bf16): fwd  2·M·K + 4·M·N ; bwd_dx  2·M·N + 4·M·K ;
+// wgrad2  2·M·K + 2·M·N.
+#include "vft_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One block = 16 token rows, 256 threads.
+//   phase 1:  p[16][r] = X[16 rows][K] · Wᵀ,  W = w1[r][K] row-major (k contiguous)
+//   phase 2:  Y[16 rows][N] += s · p · W2,    W2(j, n):  NJ layout  w2[n*r + j]   (fwd: lora_up (N,r))
+//                                                        JN layout  w2[j*N + n]   (bwd: lora_down (r,K))
+// RC = rank chunk held in registers (>= r for the shipped ranks 4 / 8 / 16).
+// ---------------------------------------------------------------------------------------------
+template <int RC, bool NJ>
+__global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
+                                                        bf16_t* __restrict__ p_out, bf16_t* __restrict__ w2t_out,
+                                                        int M, int K, int N, int r, int64_t ldx, int64_t ldy, float s) {
+    __shared__ float red[4][16][17];
+    __shared__ float ps[16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * 16;
+    // ---- phase 1 ----
+    {
+        const int row = m0 + (lane & 15);
+        const int q = lane >> 4;
+        const int j = lane & 15;
+        const bool rok = row < M, jok = j < r;
+        const bf16_t* xr = x + (int64_t)row * ldx;
+        const bf16_t* wr = w1 + (int64_t)j * K;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int nks = (K + 31) / 32;
+#pragma unroll 4
+        for (int ks = wv; ks < nks; ks += 4) {
+            const int k = ks * 32 + 8 * q;
+            bf16x8 a = zero8(), b = zero8();
+            if (k < K) {
+                if (rok) a = *reinterpret_cast<const bf16x8*>(xr + k);
+                if (jok) b = *reinterpret_cast<const bf16x8*>(wr + k);
+            }
+            acc = mfma16(a, b, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wv][q * 4 + i][j] = acc[i];
+    }
+    __syncthreads();
+    {
+        const int row = tid >> 4, j = tid & 15;
+        const float v = red[0][row][j] + red[1][row][j] + red[2][row][j] + red[3][row][j];
+        ps[row][j] = v;
+        if (p_out != nullptr && j < r && m0 + row < M) p_out[(int64_t)(m0 + row) * r + j] = (bf16_t)v;
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const int nrows = min(16, M - m0);
+    for (int n0 = tid * 8; n0 < N; n0 += 2048) {
+        for (int j0 = 0; j0 < r; j0 += RC) {
+            float wreg[8][RC];
+            if (NJ) {
+                // w2[n*r + j]: the 8 columns' coefficients are one contiguous run of 8*r elements
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int j = 0; j < RC; ++j)
+                        wreg[c][j] = (j0 + j < r) ? s * (float)w2[(int64_t)(n0 + c) * r + j0 + j] : 0.f;
+                if (w2t_out != nullptr && blockIdx.x == 0) {
+#pragma unroll
+                    for (int j = 0; j < RC; ++j)
+                        if (j0 + j < r) {
+                            bf16x8 v;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) v[c] = w2[(int64_t)(n0 + c) * r + j0 + j];
+                            *reinterpret_cast<bf16x8*>(w2t_out + (int64_t)(j0 + j) * N + n0) = v;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RC; ++j) {
+                    bf16x8 v = zero8();
+                    if (j0 + j < r) v = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(j0 + j) * N + n0);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) wreg[c][j] = s * (float)v[c];
+                }
+            }
+            for (int i = 0; i < nrows; ++i) {
+                bf16_t* yp = y + (int64_t)(m0 + i) * ldy + n0;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(yp);
+                float tv[RC];
+#pragma unroll
+                for (int j = 0; j < RC; ++j) tv[j] = (j0 + j < 16) ? ps[i][(j0 + j) & 15] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float a = (float)v[c];
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) a = fmaf(tv[j], wreg[c][j], a);
+                    v[c] = (bf16_t)a;
+                }
+                *reinterpret_cast<bf16x8*>(yp) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad stage 1: P[mb][k][j] = Σ_{m in 256-row block mb} X[m][k] · T[m][j]     (fp32, r <= 32)
+// Gᵀ tile (32 k x 32 j) per MFMA: A = Xᵀ via ds_read_b64_tr_b16 of the row-major staged X tile,
+// B = T rows gathered in the accumulator-k order.  block = 4 waves; 64 rows per iteration, 16 per
+// wave; K tile = 128 columns.  Waves are reduced through LDS, so one partial per block.
+// blockIdx.z selects the problem (0: X=x,T=u -> dA ; 1: X=dy,T=t -> dB).
+// ---------------------------------------------------------------------------------------------
+constexpr int WG_ROWS = 256, WG_COLS = 128, WG_LD = WG_COLS + 8;
+
+struct WgradProblem {
+    const bf16_t* x;
+    const bf16_t* t;
+    float* part;
+    bf16_t* out;
+    int K;
+    int64_t ldx, oj, ok;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0, int col0, int lane) {
+    const int h = lane >> 5;
+    const int i = lane & 15;
+    const bf16_t* a0 = tile + (row0 + 4 * h + (i >> 2)) * ld + col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * ld));
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+__global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);                    // [64][WG_LD]
+    float* Red = reinterpret_cast<float*>(smem + 64 * WG_LD * 2);    // [3][4][16][64]
+    const WgradProblem& p = blockIdx.z == 0 ? p0 : p1;
+    const int K = p.K;
+    const int k0 = blockIdx.x * WG_COLS;
+    if (k0 >= K) return;  // block-uniform
+    const bf16_t* __restrict__ x = p.x;
+    const bf16_t* __restrict__ t = p.t;
+    const int64_t ldx = p.ldx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, j = lane & 31;
+    const int mb = blockIdx.y;
+    const int mstart = mb * WG_ROWS;
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+    for (int it = 0; it < WG_ROWS / 64; ++it) {
+        const int r0 = mstart + it * 64;
+        if (r0 >= M) break;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * 256 + tid;
+            const int row = c / 16, col = (c % 16) * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r0 + row < M && k0 + col < K) v = *reinterpret_cast<const u32x4*>(x + (int64_t)(r0 + row) * ldx + k0 + col);
+            *reinterpret_cast<u32x4*>(Xs + row * WG_LD + col) = v;
+        }
+        __syncthreads();
+        bf16x8 b = zero8();
+        if (j < r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = r0 + wv * 16 + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (m < M) b[i] = t[(int64_t)m * r + j];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 a = tr_frag(Xs, WG_LD, wv * 16, c * 32, lane);
+            acc[c] = mfma32(a, b, acc[c]);
+        }
+    }
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Red[(((wv - 1) * 4 + c) * 16 + i) * 64 + lane] = acc[c][i];
+    }
+    __syncthreads();
+    if (wv == 0 && j < r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = acc[c][i];
+#pragma unroll
+                for (int ww = 0; ww < 3; ++ww) v += Red[((ww * 4 + c) * 16 + i) * 64 + lane];
+                const int k = k0 + c * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (k < K) p.part[((int64_t)mb * K + k) * r + j] = v;
+            }
+    }
+}
+
+// stage 2: out(j, k) = s · Σ_mb P[mb][k][j]   (bf16, strided output), both problems in one launch
+__global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(WgradProblem p0, WgradProblem p1, int nmb, int r, float s) {
+    const WgradProblem& p = blockIdx.y == 0 ? p0 : p1;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ne = (int64_t)p.K * r;
+    if (e >= ne) return;
+    float v = 0.f;
+    for (int mb = 0; mb < nmb; ++mb) v += p.part[(int64_t)mb * ne + e];
+    const int k = (int)(e / r), j = (int)(e % r);
+    p.out[(int64_t)j * p.oj + (int64_t)k * p.ok] = (bf16_t)(v * s);
+}
+
+int chk(bool c, const char* msg) {
+    if (!c) vft_set_error("%s", msg);
+    return c ? 0 : 1;
+}
+
+template <bool NJ>
+int launch_rows(const void* x, void* y, const void* w1, const void* w2, void* p_out, void* w2t_out, int M, int K, int N,
+                int r, int64_t ldx, int64_t ldy, float s, hipStream_t st) {
+    dim3 grid((M + 15) / 16), block(256);
+#define VFT_ROWS(RC)                                                                                                  \
+    hipLaunchKernelGGL((lora_rows_kernel<RC, NJ>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)w1, \
+                       (const bf16_t*)w2, (bf16_t*)p_out, (bf16_t*)w2t_out, M, K, N, r, ldx, ldy, s)
+    if (r <= 4)
+        VFT_ROWS(4);
+    else if (r <= 8)
+        VFT_ROWS(8);
+    else
+        VFT_ROWS(16);
+#undef VFT_ROWS
+    return 0;
+}
+
+int check_rows(const char* name, const void* x, const void* y, int M, int K, int N, int r, int64_t ldx, int64_t ldy) {
+    VFT_CHECK_ARG(M > 0 && K > 0 && N > 0 && r > 0 && r <= 16, "%s: need M,K,N>0 and 0<r<=16 (got M=%d K=%d N=%d r=%d)", name, M, K, N, r);
+    VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "%s: K, N and row strides must be multiples of 8", name);
+    VFT_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "%s: activations must be 16-byte aligned", name);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora_up, void* t_out,
+                            void* up_t_out, int M, int K, int N, int r, int64_t ldx, int64_t ldy, float scale,
+                            void* stream) {
+    if (chk(x && y && lora_down && lora_up, "vft_lora_fwd: null pointer")) return 1;
+    if (check_rows("vft_lora_fwd", x, y, M, K, N, r, ldx, ldy)) return 1;
+    VFT_CHECK_ARG(((uintptr_t)lora_down & 15) == 0 && ((uintptr_t)up_t_out & 15) == 0, "vft_lora_fwd: lora_down / up_t_out must be 16-byte aligned");
+    launch_rows<true>(x, y, lora_down, lora_up, t_out, up_t_out, M, K, N, r, ldx, ldy, scale, (hipStream_t)stream);
+    VFT_CHECK_LAUNCH("vft_lora_fwd");
+    return 0;
+}
+
+extern "C" int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
+                               int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream) {
+    if (chk(dy && dx && lora_up_t && lora_down && u_out, "vft_lora_bwd_dx: null pointer")) return 1;
+    if (check_rows("vft_lora_bwd_dx", dy, dx, M, N, K, r, lddy, lddx)) return 1;
+    VFT_CHECK_ARG(((uintptr_t)lora_up_t & 15) == 0 && ((uintptr_t)lora_down & 15) == 0, "vft_lora_bwd_dx: weights must be 16-byte aligned");
+    // phase 1 contracts over N with Bᵀ (r,N); phase 2 streams dx (M,K) with A (r,K) in JN layout
+    launch_rows<false>(dy, dx, lora_up_t, lora_down, u_out, nullptr, M, N, K, r, lddy, lddx, scale, (hipStream_t)stream);
+    VFT_CHECK_LAUNCH("vft_lora_bwd_dx");
+    return 0;
+}
+
+extern "C" size_t vft_lora_wgrad_workspace(int M, int K, int N, int r) {
+    return (size_t)((M + WG_ROWS - 1) / WG_ROWS) * (size_t)(K + N) * (size_t)r * sizeof(float);
+}
+
+extern "C" int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t, void* d_down, void* d_up,
+                               float* workspace, size_t ws_bytes, int M, int K, int N, int r, int64_t ldx, int64_t lddy,
+                               float scale, void* stream) {
+    if (chk(x && u && dy && t && d_down && d_up && workspace, "vft_lora_wgrad2: null pointer")) return 1;
+    VFT_CHECK_ARG(M > 0 && K > 0 && N > 0 && r > 0 && r <= 32, "vft_lora_wgrad2: need M,K,N>0 and 0<r<=32");
+    VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "vft_lora_wgrad2: K, N, strides must be multiples of 8");
+    VFT_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "vft_lora_wgrad2: activations must be 16-byte aligned");
+    VFT_CHECK_ARG(ws_bytes >= vft_lora_wgrad_workspace(M, K, N, r), "vft_lora_wgrad2: workspace too small");
+    const int nmb = (M + WG_ROWS - 1) / WG_ROWS;
+    WgradProblem pa{(const bf16_t*)x, (const bf16_t*)u, workspace, (bf16_t*)d_down, K, ldx, (int64_t)K, 1};  // dA (r,K)
+    WgradProblem pb{(const bf16_t*)dy, (const bf16_t*)t, workspace + (size_t)nmb * K * r, (bf16_t*)d_up, N, lddy, 1,
+                    (int64_t)r};  // dB (N,r)
+    constexpr size_t lds = 64 * WG_LD * 2 + 3 * 4 * 16 * 64 * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lora_wgrad_partial_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int kmax = K > N ? K : N;
+    hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, 2), dim3(256), lds,
+                       (hipStream_t)stream, pa, pb, M, r);
+    VFT_CHECK_LAUNCH("vft_lora_wgrad2(partial)");
+    const int64_t ne = (int64_t)kmax * r;
+    hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 2), dim3(256), 0,
+                       (hipStream_t)stream, pa, pb, nmb, r, scale);
+    VFT_CHECK_LAUNCH("vft_lora_wgrad2(reduce)");
+    return 0;
+}

@@ -174,93 +174,445 @@ def _ready(*tensors: torch.Tensor) -> None:
             raise RuntimeError(f"vision_ft_amd kernels run on MI355X only (tensor on {t.device}); no CPU fallback")
 
 
+KIND_LAYER, KIND_RMS, KIND_NONE = 0, 1, 2
+
+
+def _bf16_or_none(t):
+    if t is None:
+        return None
+    return t if (t.dtype == torch.bfloat16 and t.is_contiguous()) else t.to(torch.bfloat16).contiguous()
+
+
+class _RowNorm(torch.autograd.Function):
+    """y = (norm(x) * w + b) * (1 + scale[b]) + shift[b] over the last dim (HIP: vft_norm_fwd / _bwd_dx).
+    Parameter / modulation gradients (only needed outside frozen-trunk LoRA runs) are reduced with
+    torch ops from the saved statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, shift, kind, eps):
+        C = x.shape[-1]
+        x2 = _rows(x)
+        rows = x2.shape[0]
+        w, b_, sc, sh = (_bf16_or_none(t) for t in (weight, bias, scale, shift))
+        rpb = rows // sc.shape[0] if sc is not None else (rows // sh.shape[0] if sh is not None else rows)
+        y = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if kind == KIND_LAYER else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _Timed("norm_fwd", 4.0 * rows * C):
+            st = _C.lib().vft_norm_fwd(_ptr(x2), _ptr(y), _ptr(w), _ptr(b_), _ptr(sc), _ptr(sh), _ptr(mean), _ptr(rstd),
+                                       rows, C, x2.stride(0), rpb, kind, float(eps), _stream())
+        _C.check(st, "vft_norm_fwd")
+        ctx.save_for_backward(x2, w, b_, sc, mean, rstd)
+        ctx.meta = (kind, rpb, x.shape, weight, bias, scale, shift)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b_, sc, mean, rstd = ctx.saved_tensors
+        kind, rpb, xshape, weight, bias, scale, shift = ctx.meta
+        rows, C = x2.shape
+        dy2 = dy.reshape(rows, C)
+        if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
+            dy2 = dy2.to(torch.bfloat16).contiguous()
+        dx = dw = db = dsc = dsh = None
+        if ctx.needs_input_grad[0]:
+            dx2 = torch.empty((rows, C), dtype=torch.bfloat16, device=dy.device)
+            with torch.cuda.device(dy.device), _Timed("norm_bwd", 6.0 * rows * C):
+                st = _C.lib().vft_norm_bwd_dx(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(sc), _ptr(mean), _ptr(rstd), _ptr(dx2),
+                                              rows, C, x2.stride(0), rpb, kind, _stream())
+            _C.check(st, "vft_norm_bwd_dx")
+            dx = dx2.view(xshape)
+        if any(ctx.needs_input_grad[1:5]):
+            xf = x2.float()
+            xh = (xf - mean[:, None]) * rstd[:, None] if kind == KIND_LAYER else xf * rstd[:, None]
+            g = dy2.float()
+            nb = rows // rpb
+            gm = g if sc is None else g * (1 + sc.float()).repeat_interleave(rpb, dim=0)
+            if ctx.needs_input_grad[1] and weight is not None:
+                dw = (gm * xh).sum(0).to(weight.dtype)
+            if ctx.needs_input_grad[2] and bias is not None:
+                db = gm.sum(0).to(bias.dtype)
+            if ctx.needs_input_grad[3] and scale is not None:
+                base = xh if w is None else xh * w.float()
+                if b_ is not None:
+                    base = base + b_.float()
+                dsc = (g * base).view(nb, rpb, C).sum(1).to(scale.dtype).view(scale.shape)
+            if ctx.needs_input_grad[4] and shift is not None:
+                dsh = g.view(nb, rpb, C).sum(1).to(shift.dtype).view(shift.shape)
+        return dx, dw, db, dsc, dsh, None, None
+
+
+def _norm(x, weight, bias, scale, shift, kind, eps):
+    _ready(x)
+    _require_gpu(x)
+    return _RowNorm.apply(x, weight, bias, scale, shift, kind, eps)
+
+
 def layer_norm(x: torch.Tensor, weight, bias, eps: float) -> torch.Tensor:
     """LayerNorm over the last dim with fp32 statistics, output in x.dtype."""
-    _ready(x)
-    w = None if weight is None else weight.float()
-    b = None if bias is None else bias.float()
-    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
+    return _norm(x, weight, bias, None, None, KIND_LAYER, eps)
 
 
 def rms_norm(x: torch.Tensor, weight, eps: float) -> torch.Tensor:
-    _ready(x)
-    return F.rms_norm(x.float(), (x.shape[-1],), None if weight is None else weight.float(), eps).to(x.dtype)
+    return _norm(x, weight, None, None, None, KIND_RMS, eps)
 
 
 def layer_norm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """AdaLN: LN(x) (no affine, fp32 stats) * (1 + scale[:,None]) + shift[:,None]   (x: B,S,C; shift/scale: B,C)."""
-    _ready(x)
-    h = F.layer_norm(x.float(), (x.shape[-1],), None, None, eps).to(x.dtype)
-    return h * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+    return _norm(x, None, None, scale, shift, KIND_LAYER, eps)
 
 
 def rms_norm_scale(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor | None, eps: float) -> torch.Tensor:
     """Lumina2 pre-norm: RMSNorm(x)*w, optionally * (1 + scale[:,None])."""
-    _ready(x)
-    h = F.rms_norm(x, (x.shape[-1],), weight, eps)
-    return h if scale is None else h * (1 + scale.unsqueeze(1))
+    return _norm(x, weight, None, scale, None, KIND_RMS, eps)
+
+
+class _GateResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, residual, gate, y, use_tanh):
+        B, S, C = y.shape
+        res2, y2, g = residual.contiguous(), y.contiguous(), _bf16_or_none(gate)
+        out = torch.empty_like(y2)
+        with torch.cuda.device(y.device), _Timed("gate_residual", 6.0 * B * S * C):
+            st = _C.lib().vft_gate_residual(_ptr(res2), _ptr(g), _ptr(y2), _ptr(out), B * S, C, S, int(use_tanh), _stream())
+        _C.check(st, "vft_gate_residual")
+        ctx.save_for_backward(g, y2)
+        ctx.use_tanh = use_tanh
+        ctx.gate_ref = gate
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, y2 = ctx.saved_tensors
+        B, S, C = y2.shape
+        d2 = dout.contiguous()
+        dres = dout if ctx.needs_input_grad[0] else None
+        dy = dgate = None
+        if ctx.needs_input_grad[2]:
+            dy = torch.empty_like(y2)
+            with torch.cuda.device(dout.device), _Timed("gate_residual_bwd", 4.0 * B * S * C):
+                st = _C.lib().vft_gate_residual(None, _ptr(g), _ptr(d2), _ptr(dy), B * S, C, S, int(ctx.use_tanh), _stream())
+            _C.check(st, "vft_gate_residual(bwd)")
+        if ctx.needs_input_grad[1]:
+            dg = (d2.float() * y2.float()).sum(1)
+            if ctx.use_tanh:
+                dg = dg * (1 - torch.tanh(g.float()) ** 2)
+            dgate = dg.to(ctx.gate_ref.dtype)
+        return dres, dgate, dy, None
 
 
 def gate_residual(residual: torch.Tensor, gate: torch.Tensor, y: torch.Tensor, tanh: bool = False) -> torch.Tensor:
     """residual + g[:,None,:] * y  with g = tanh(gate) if `tanh`."""
     _ready(residual)
-    g = gate.tanh() if tanh else gate
-    return residual + g.unsqueeze(1) * y
+    _require_gpu(residual, y)
+    return _GateResidual.apply(residual, gate, y, tanh)
+
+
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu):
+        N, C, H, W = x.shape
+        x = x.contiguous()
+        w, b_ = _bf16_or_none(weight), _bf16_or_none(bias)
+        y = torch.empty_like(x)
+        stats = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _Timed("groupnorm_fwd", 6.0 * x.numel()):
+            st = _C.lib().vft_groupnorm_fwd(_ptr(x), _ptr(y), _ptr(w), _ptr(b_), _ptr(stats), N, C, H * W, groups,
+                                            float(eps), int(silu), _stream())
+        _C.check(st, "vft_groupnorm_fwd")
+        ctx.save_for_backward(x, w, b_, stats)
+        ctx.meta = (groups, eps, silu, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b_, stats = ctx.saved_tensors
+        groups, eps, silu, weight, bias = ctx.meta
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        bstats = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+        need_w = ctx.needs_input_grad[1] and weight is not None
+        need_b = ctx.needs_input_grad[2] and bias is not None
+        dwf = torch.empty(C, dtype=torch.float32, device=x.device) if need_w else None
+        dbf = torch.empty(C, dtype=torch.float32, device=x.device) if need_b else None
+        with torch.cuda.device(x.device), _Timed("groupnorm_bwd", 10.0 * x.numel()):
+            st = _C.lib().vft_groupnorm_bwd(_ptr(x), _ptr(dy), _ptr(stats), _ptr(w), _ptr(b_), _ptr(dx), _ptr(bstats),
+                                            _ptr(dwf), _ptr(dbf), N, C, H * W, groups, float(eps), int(silu), _stream())
+        _C.check(st, "vft_groupnorm_bwd")
+        dw = dwf.to(weight.dtype) if need_w else None
+        db = dbf.to(bias.dtype) if need_b else None
+        return dx, dw, db, None, None, None
 
 
 def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: bool = False) -> torch.Tensor:
     """GroupNorm over NCHW (fp32 statistics) with optional fused SiLU."""
     _ready(x)
-    h = F.group_norm(x, groups, weight, bias, eps)
-    return F.silu(h) if silu else h
+    _require_gpu(x)
+    if (x.shape[2] * x.shape[3]) % 8 != 0:
+        raise ValueError("group_norm: H*W must be a multiple of 8")
+    return _GroupNorm.apply(x, weight, bias, groups, eps, silu)
+
+
+class _GeGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj):
+        F2 = proj.shape[-1]
+        p2 = _rows(proj)
+        if p2.stride(0) != F2:
+            p2 = p2.contiguous()
+        M, Fh = p2.shape[0], F2 // 2
+        out = torch.empty((M, Fh), dtype=torch.bfloat16, device=proj.device)
+        with torch.cuda.device(proj.device), _Timed("geglu_fwd", 6.0 * M * Fh):
+            st = _C.lib().vft_geglu_fwd(_ptr(p2), _ptr(out), M, Fh, _stream())
+        _C.check(st, "vft_geglu_fwd")
+        ctx.save_for_backward(p2)
+        ctx.pshape = proj.shape
+        return out.view(*proj.shape[:-1], Fh)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (p2,) = ctx.saved_tensors
+        M, F2 = p2.shape
+        d2 = dy.reshape(M, F2 // 2).contiguous()
+        dproj = torch.empty_like(p2)
+        with torch.cuda.device(dy.device), _Timed("geglu_bwd", 10.0 * M * (F2 // 2)):
+            st = _C.lib().vft_geglu_bwd(_ptr(p2), _ptr(d2), _ptr(dproj), M, F2 // 2, _stream())
+        _C.check(st, "vft_geglu_bwd")
+        return dproj.view(ctx.pshape)
 
 
 def geglu(proj: torch.Tensor) -> torch.Tensor:
     """proj (..., 2F) -> proj[..., :F] * gelu(proj[..., F:])  (exact erf GELU)."""
     _ready(proj)
-    a, g = proj.chunk(2, dim=-1)
-    return a * F.gelu(g)
+    _require_gpu(proj)
+    return _GeGLU.apply(proj)
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a2)
+        with torch.cuda.device(a.device), _Timed("swiglu_fwd", 6.0 * a2.numel()):
+            st = _C.lib().vft_swiglu_fwd(_ptr(a2), _ptr(b2), _ptr(out), a2.numel(), _stream())
+        _C.check(st, "vft_swiglu_fwd")
+        ctx.save_for_backward(a2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, b2 = ctx.saved_tensors
+        d2 = dy.contiguous()
+        da, db = torch.empty_like(a2), torch.empty_like(b2)
+        with torch.cuda.device(dy.device), _Timed("swiglu_bwd", 10.0 * a2.numel()):
+            st = _C.lib().vft_swiglu_bwd(_ptr(a2), _ptr(b2), _ptr(d2), _ptr(da), _ptr(db), a2.numel(), _stream())
+        _C.check(st, "vft_swiglu_bwd")
+        return da, db
 
 
 def swiglu(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """silu(a) * b"""
-    _ready(a)
-    return F.silu(a) * b
+    _ready(a, b)
+    _require_gpu(a, b)
+    return _SwiGLU.apply(a, b)
+
+
+class _QkNormRope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, cos, sin, kind, eps):
+        B, S, H, D = x.shape
+        if x.stride(3) != 1 or any(st % 8 for st in x.stride()[:3]) or x.data_ptr() % 16:
+            x = x.contiguous()
+        w = _bf16_or_none(weight)
+        cs_b = 0
+        if cos is not None:
+            cos, sin = cos.float().contiguous(), sin.float().contiguous()
+            if cos.dim() == 3:
+                cs_b = cos.stride(0)
+        y = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty(B * S * H, dtype=torch.float32, device=x.device) if kind == KIND_LAYER else None
+        rstd = torch.empty(B * S * H, dtype=torch.float32, device=x.device) if kind != KIND_NONE else None
+        with torch.cuda.device(x.device), _Timed("qk_norm_rope_fwd", 4.0 * x.numel()):
+            st = _C.lib().vft_qk_norm_rope_fwd(_ptr(x), _ptr(y), _ptr(w), _ptr(cos), _ptr(sin), _ptr(mean), _ptr(rstd),
+                                               B, S, H, D, _C.i64x3(x.stride()[:3]), cs_b, kind, float(eps), _stream())
+        _C.check(st, "vft_qk_norm_rope_fwd")
+        ctx.save_for_backward(x, w, cos, sin, mean, rstd)
+        ctx.meta = (kind, cs_b, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, cos, sin, mean, rstd = ctx.saved_tensors
+        kind, cs_b, weight = ctx.meta
+        B, S, H, D = x.shape
+        d2 = dy.contiguous()
+        dx = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device), _Timed("qk_norm_rope_bwd", 6.0 * x.numel()):
+            st = _C.lib().vft_qk_norm_rope_bwd(_ptr(d2), _ptr(x), _ptr(w), _ptr(cos), _ptr(sin), _ptr(mean), _ptr(rstd),
+                                               _ptr(dx), B, S, H, D, _C.i64x3(x.stride()[:3]), cs_b, kind, _stream())
+        _C.check(st, "vft_qk_norm_rope_bwd")
+        dw = None
+        if ctx.needs_input_grad[1] and weight is not None:
+            g = d2.float()
+            if cos is not None:
+                c = cos.unsqueeze(-2) if cos.dim() == 3 else cos.unsqueeze(0).unsqueeze(-2)
+                s_ = sin.unsqueeze(-2) if sin.dim() == 3 else sin.unsqueeze(0).unsqueeze(-2)
+                ge, go = g[..., 0::2], g[..., 1::2]
+                g = torch.stack((ge * c + go * s_, -ge * s_ + go * c), dim=-1).reshape(g.shape)
+            xh = x.float() * rstd.view(B, S, H, 1)
+            dw = (g * xh).sum((0, 1, 2)).to(weight.dtype)
+        return dx, dw, None, None, None, None
+
+
+_QK_KINDS = {"layer": KIND_LAYER, "rms": KIND_RMS, "none": KIND_NONE}
+
+
+def qk_norm_rope(x: torch.Tensor, kind: str, weight, eps: float, cos: torch.Tensor | None, sin: torch.Tensor | None) -> torch.Tensor:
+    """Per-head norm over head_dim ('layer': LN without affine; 'rms': RMSNorm * weight; 'none') followed
+    by the interleaved-pair rotation, one fused kernel.  x: (B,S,H,D) (any 8-aligned strides);
+    cos/sin: (S,D/2) or (B,S,D/2) fp32, or None.  Returns contiguous (B,S,H,D)."""
+    _ready(x)
+    _require_gpu(x)
+    if kind not in _QK_KINDS:
+        raise ValueError(f"unknown qk norm kind {kind!r}")
+    if x.shape[-1] not in (64, 96, 128, 256):
+        raise ValueError(f"head_dim {x.shape[-1]} unsupported (64, 96, 128, 256)")
+    if cos is not None and cos.shape[-1] * 2 != x.shape[-1]:
+        raise ValueError("rope table must have head_dim/2 columns")
+    return _QkNormRope.apply(x, weight, cos, sin, _QK_KINDS[kind], eps)
 
 
 def rope_apply(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
     """Rotate interleaved pairs of the last dim in fp32. x (B,H,S,D); freqs (S,D/2,2) = [cos, sin]."""
-    _ready(x)
-    cos, sin = freqs[..., 0].to(x.device), freqs[..., 1].to(x.device)
-    xf = x.float()
-    xe, xo = xf[..., 0::2], xf[..., 1::2]
-    return torch.stack((xe * cos - xo * sin, xe * sin + xo * cos), dim=-1).reshape(x.shape).to(x.dtype)
+    f = freqs.to(x.device)
+    out = qk_norm_rope(x.transpose(1, 2), "none", None, 0.0, f[..., 0], f[..., 1])
+    return out.transpose(1, 2)
 
 
-def qk_norm_rope(x: torch.Tensor, kind: str, weight, eps: float, cos: torch.Tensor | None, sin: torch.Tensor | None) -> torch.Tensor:
-    """Per-head norm over head_dim ('layer': LN without affine; 'rms': RMSNorm * weight) followed by
-    the interleaved-pair rotation.  x: (B,S,H,D); cos/sin: (S,D/2) or (B,S,D/2) fp32, or None."""
-    _ready(x)
-    d = x.shape[-1]
-    if kind == "layer":
-        h = F.layer_norm(x.float(), (d,), None, None, eps).to(x.dtype)
-    elif kind == "rms":
-        h = F.rms_norm(x, (d,), weight, eps)
-    elif kind == "none":
-        h = x
-    else:
-        raise ValueError(kind)
-    if cos is None:
-        return h
-    c = cos.unsqueeze(-2)  # broadcast over heads
-    s = sin.unsqueeze(-2)
-    hf = h.float()
-    he, ho = hf[..., 0::2], hf[..., 1::2]
-    return torch.stack((he * c - ho * s, he * s + ho * c), dim=-1).reshape(h.shape).to(h.dtype)
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    return x2
+
+
+def _lora_fwd_(x2: torch.Tensor, y2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, s: float):
+    """y2 += s (x2 Aᵀ) Bᵀ in place; returns (t = x2 Aᵀ, Bᵀ) for backward."""
+    M, K = x2.shape
+    N, r = B.shape
+    t = torch.empty((M, r), dtype=torch.bfloat16, device=x2.device)
+    Bt = torch.empty((r, N), dtype=torch.bfloat16, device=x2.device)
+    with _Timed("lora_fwd", 2.0 * M * K + 4.0 * M * N):
+        st = _C.lib().vft_lora_fwd(_ptr(x2), _ptr(y2), _ptr(A), _ptr(B), _ptr(t), _ptr(Bt), M, K, N, r,
+                                   x2.stride(0), y2.stride(0), float(s), _stream())
+    _C.check(st, "vft_lora_fwd")
+    return t, Bt
+
+
+def _lora_bwd_dx_(dy2: torch.Tensor, dx2: torch.Tensor, Bt: torch.Tensor, A: torch.Tensor, s: float) -> torch.Tensor:
+    """dx2 += s (dy2 B) A in place; returns u = dy2 B."""
+    M, N = dy2.shape
+    r, K = A.shape
+    u = torch.empty((M, r), dtype=torch.bfloat16, device=dy2.device)
+    with _Timed("lora_bwd_dx", 2.0 * M * N + 4.0 * M * K):
+        st = _C.lib().vft_lora_bwd_dx(_ptr(dy2), _ptr(dx2), _ptr(Bt), _ptr(A), _ptr(u), M, N, K, r,
+                                      dy2.stride(0), dx2.stride(0), float(s), _stream())
+    _C.check(st, "vft_lora_bwd_dx")
+    return u
+
+
+def _lora_wgrad2(x2, u, dy2, t, A, B, s: float):
+    M, K = x2.shape
+    N, r = B.shape
+    dA, dB = torch.empty_like(A), torch.empty_like(B)
+    nbytes = _C.lib().vft_lora_wgrad_workspace(M, K, N, r)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
+    with _Timed("lora_wgrad2", 2.0 * M * (K + N)):
+        st = _C.lib().vft_lora_wgrad2(_ptr(x2), _ptr(u), _ptr(dy2), _ptr(t), _ptr(dA), _ptr(dB), _ptr(ws), nbytes,
+                                      M, K, N, r, x2.stride(0), dy2.stride(0), float(s), _stream())
+    _C.check(st, "vft_lora_wgrad2")
+    return dA, dB
+
+
+class _LoRALinear(torch.autograd.Function):
+    """y = x Wᵀ + b + s·(x Aᵀ) Bᵀ with a frozen base (W, b).  The base products are library GEMMs;
+    everything rank-sized is the HIP kernels above, applied in place on the GEMM outputs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, A, B, s):
+        x2 = _rows(x)
+        A, B = A.contiguous(), B.contiguous()
+        with torch.cuda.device(x.device):
+            y2 = F.linear(x2, weight, bias)
+            t, Bt = _lora_fwd_(x2, y2, A, B, s)
+        ctx.save_for_backward(x2, t, Bt, weight, A, B)
+        ctx.s = s
+        ctx.xshape = x.shape
+        return y2.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t, Bt, weight, A, B = ctx.saved_tensors
+        s = ctx.s
+        dy2 = _rows(dy)
+        dx = dA = dB = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[0]:
+                dx2 = dy2 @ weight
+                u = _lora_bwd_dx_(dy2, dx2, Bt, A, s)
+                dx = dx2.view(ctx.xshape)
+            else:  # input of a frozen trunk's first adapted layer: dx is unused, u = dy·B still needed
+                scratch = torch.empty((dy2.shape[0], A.shape[1]), dtype=dy.dtype, device=dy.device)
+                u = _lora_bwd_dx_(dy2, scratch, Bt, A, s)
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B, s)
+        return dx, None, None, dA, dB, None
+
+
+class _LoRABranch(torch.autograd.Function):
+    """y += s·(x Aᵀ) Bᵀ in place on the output of an arbitrary base layer (e.g. the NF4 linear)."""
+
+    @staticmethod
+    def forward(ctx, x, y, A, B, s):
+        x2 = _rows(x)
+        y2 = y.view(-1, y.shape[-1])
+        A, B = A.contiguous(), B.contiguous()
+        with torch.cuda.device(x.device):
+            t, Bt = _lora_fwd_(x2, y2, A, B, s)
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(x2, t, Bt, A, B)
+        ctx.s = s
+        ctx.xshape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t, Bt, A, B = ctx.saved_tensors
+        s = ctx.s
+        dy2 = _rows(dy)
+        dA = dB = None
+        with torch.cuda.device(dy.device):
+            dx2 = torch.zeros((x2.shape[0], x2.shape[1]), dtype=dy.dtype, device=dy.device)
+            u = _lora_bwd_dx_(dy2, dx2, Bt, A, s)
+            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+                dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B, s)
+        dx = dx2.view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return dx, dy, dA, dB, None
 
 
 def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.Tensor, scale: float) -> torch.Tensor:
-    """base(x) + scale * (x @ lora_down^T) @ lora_up^T"""
-    _ready(x)
+    """base(x) + scale * (x @ lora_down^T) @ lora_up^T with the rank-sized work in fused HIP kernels.
+
+    `base` is the wrapped layer: a plain ``nn.Linear`` takes the fully fused path (dx is produced in
+    one buffer); anything else (NF4 linear, ...) gets the in-place low-rank branch on its output."""
+    _ready(x, lora_down, lora_up)
+    _require_gpu(x, lora_down, lora_up)
+    if lora_down.shape[0] > 16:
+        raise ValueError(f"LoRA rank {lora_down.shape[0]} > 16 is not supported by the MI355X kernels")
+    if type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16:
+        return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale))
     y = base(x)
-    return y + F.linear(F.linear(x, lora_down), lora_up) * scale
+    if not y.is_contiguous():
+        y = y.contiguous()
+    return _LoRABranch.apply(x, y, lora_down, lora_up, float(scale))
