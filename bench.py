@@ -149,7 +149,7 @@ def main():
     from vision_ft_amd import kernels
     from vision_ft_amd.trainer.dp import DataParallelGrads
 
-    batch = args.batch or {"sdxl_lora": 4, "sdxl_full": 4, "aura_lora": 2, "lumina_lora": 2}[args.workload]
+    batch = args.batch or {"sdxl_lora": 16, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4}[args.workload]
     model = build(args.workload, device)
     params = [p for p in model.parameters() if p.requires_grad]
     dp = DataParallelGrads(params)

@@ -122,7 +122,7 @@ int vft_qk_norm_rope_bwd(const void* dy, const void* x, const void* weight, cons
 /* ---- GroupNorm (+SiLU), NCHW ---------------------------------------------------------------
  * Replaces GroupNorm -> SiLU of the SDXL ResidualBlock (sdxl/denoiser.py:511-551) and the
  * SpatialTransformer norm (:303).  stats/bstats: fp32 [N*G*2] workspaces; dweight/dbias: optional
- * fp32 [C] accumulators.  H*W must be a multiple of 8.
+ * fp32 [C] accumulators.  Accesses are 16 bytes wide when H*W is a multiple of 8 (narrower otherwise).
  */
 int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats,
                       int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);

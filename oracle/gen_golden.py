@@ -510,6 +510,21 @@ def gen_index():
         full["lumina_r4"] = targets(lum.Denoiser(lcfg.DenoiserConfig()), ["attention", "feed_forward"],
                                     ["text_encoder", "vae", "noise_refiner"], 4)
     J["full_size_targets"] = full
+
+    # SDXL checkpoint / ComfyUI key renaming (src/models/sdxl/util.py)
+    u = importlib.import_module("src.models.sdxl.util")
+    keys = ["denoiser.input_blocks.blocks.4.1.transformer_blocks.0.attn1.to_q.lora_down.weight",
+            "denoiser.middle_block.blocks.1.transformer_blocks.9.ff.net.0.proj.lora_up.weight",
+            "denoiser.output_blocks.blocks.3.1.proj_in.alpha", "denoiser.time_embed.0.weight",
+            "text_encoder.text_encoder_1.x.y", "text_encoder.text_encoder_2.a", "vae.decoder.z"]
+    orig = ["input_blocks.1.0.in_layers.0.weight", "middle_block.1.norm.bias", "output_blocks.8.0.skip_connection.weight",
+            "out.2.bias"]
+    J["sdxl_keys"] = {
+        "comfy": [[k, u.convert_to_comfy_key(k)] for k in keys],
+        "from_original": [[k, u.denoiser_convert_from_original_key(k)] for k in orig],
+        "to_original": [[u.denoiser_convert_from_original_key(k),
+                         u.denoiser_convert_to_original_key(u.denoiser_convert_from_original_key(k))] for k in orig],
+    }
     with open(os.path.join(OUT, "index.json"), "w") as f:
         json.dump(J, f)
     print("index: sdxl wrapped", len(full["sdxl_r4"]["wrapped"]), full["sdxl_r4"]["lora_params"],

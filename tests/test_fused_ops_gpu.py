@@ -62,7 +62,8 @@ def test_layer_norm_modulate_and_rms_scale(gpu):
 
 
 @pytest.mark.parametrize("N,C,H,W,silu,eps", [(2, 320, 32, 32, True, 1e-5), (3, 640, 16, 24, False, 1e-6),
-                                               (1, 1280, 8, 8, True, 1e-5), (2, 64, 4, 4, True, 1e-5)])
+                                               (1, 1280, 8, 8, True, 1e-5), (2, 64, 4, 4, True, 1e-5),
+                                               (2, 128, 6, 10, True, 1e-5), (1, 64, 3, 5, False, 1e-5)])
 def test_group_norm_silu(gpu, N, C, H, W, silu, eps):
     from vision_ft_amd import kernels
 

@@ -1,0 +1,250 @@
+"""CPU tests of the host-side mirror: integer/string work bit-exact against reference goldens,
+PEFT replacement semantics (mirroring the reference's tests/test_peft.py, test_utils.py,
+test_config.py), C-ABI library symbols, and fail-loud behaviour without a GPU."""
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from .helpers import load_index
+
+
+@pytest.fixture(scope="module")
+def J():
+    return load_index()
+
+
+# ---- buckets -------------------------------------------------------------------------------
+def test_generate_buckets_bit_exact(J):
+    from vision_ft_amd.dataset.aspect_ratio_bucket import generate_buckets
+
+    for name, rec in J["buckets"].items():
+        assert generate_buckets(**rec["kwargs"]).tolist() == rec["rows"], name
+
+
+def test_find_nearest_bit_exact(J):
+    from vision_ft_amd.dataset.aspect_ratio_bucket import AspectRatioBucketManager
+
+    for key in ("find_nearest", "find_nearest_128"):
+        rec = J[key]
+        mgr = AspectRatioBucketManager(np.array(J["buckets"][rec["bucket_set"]]["rows"]))
+        for w, h, want in rec["cases"]:
+            assert mgr.find_nearest(w, h) == want, (key, w, h)
+
+
+def test_bucket_dataset_batches_and_collate(J):
+    from vision_ft_amd.dataloader import concatnate_collate_fn
+    from vision_ft_amd.dataset.bucket import Bucket, BucketDataset
+
+    class B(Bucket):
+        pass
+
+    for key, want in J["bucket_batches"].items():
+        n, bs, rep = (int(v) for v in key.split("_"))
+        ds = BucketDataset(B(np.arange(n), batch_size=bs, num_repeats=rep))
+        assert [np.asarray(ds[i]).tolist() for i in range(len(ds))] == want, key
+    col = concatnate_collate_fn([{"a": torch.arange(6).view(2, 3), "c": ["x", "y"]}, {"a": torch.arange(6, 9).view(1, 3), "c": ["z"]}])
+    assert col["a"].tolist() == J["collate"]["a"] and col["c"] == J["collate"]["c"]
+
+
+def test_headline_bucket_set():
+    from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig, headline_buckets
+
+    assert headline_buckets() == [(640, 1536), (768, 1280), (768, 1408), (896, 1152), (1024, 1024), (1152, 896),
+                                  (1280, 768), (1408, 768), (1536, 640)]  # BASELINE config 5
+    ds = SyntheticLatentDatasetConfig(batch_size=4, step=128, samples_per_bucket=8).get_dataset()
+    assert len(ds) == 9 * 2
+    item = ds[0]
+    assert set(item) == {"width", "height", "seeds"} and len(item["seeds"]) == 4
+
+
+# ---- target keys / peft ---------------------------------------------------------------------
+def _conv(L):
+    from vision_ft_amd.utils.state_dict import RegexMatch
+
+    return [RegexMatch(regex=p["regex"]) if isinstance(p, dict) else p for p in L]
+
+
+def test_get_target_keys_bit_exact(J):
+    from vision_ft_amd.utils.state_dict import get_target_keys
+
+    keys = J["target_keys"]["keys"]
+    for case in J["target_keys"]["cases"]:
+        assert sorted(get_target_keys(_conv(case["include"]), _conv(case["exclude"]), keys)) == case["result"], case
+
+
+@pytest.mark.parametrize("name,family", [("sdxl_r4", "sdxl"), ("aura_yaml_r16", "auraflow"), ("aura_debug_r16", "auraflow"),
+                                         ("lumina_r4", "lumina2")])
+def test_full_size_lora_targets_match_reference(J, name, family):
+    """Same wrapped modules, same LoRA parameter count, same adapter key names as the reference on the
+    full-size models (700 / 124 / 252 / 140 Linears)."""
+    import importlib
+
+    from vision_ft_amd.modules.peft import LoRAConfig, PeftTargetConfig, get_adapter_parameters
+
+    rec = J["full_size_targets"][name]
+    mod = importlib.import_module(f"vision_ft_amd.models.{family}")
+    with torch.device("meta"):
+        model = mod.Denoiser(mod.DenoiserConfig())
+        assert len([n for n, _ in model.named_modules()]) == rec["n_modules"]
+        PeftTargetConfig(include_keys=_conv(rec["include"]), exclude_keys=_conv(rec["exclude"]),
+                         config=LoRAConfig(rank=rec["rank"])).replace_to_peft_layer(model)
+    wrapped = sorted(n for n, m in model.named_modules() if hasattr(m, "lora_down"))
+    assert wrapped == rec["wrapped"]
+    assert sum(p.numel() for n, p in model.named_parameters() if "lora_" in n) == rec["lora_params"]
+    assert sorted(get_adapter_parameters(model).keys())[:12] == rec["adapter_keys_head"]
+
+
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layer1 = nn.Sequential(nn.Linear(10, 10), nn.ReLU())
+        self.child = nn.ModuleDict({"child_1": nn.Linear(10, 10), "child_2": nn.Linear(10, 10)})
+        self.last_layer = nn.Sequential(nn.Linear(10, 10))
+
+
+def test_lora_replacement_semantics():
+    """Mirrors the reference's tests/test_peft.py:25-126: targets, shapes, zero-init no-op,
+    trainability flags, adapter keys."""
+    from vision_ft_amd.modules.peft import LoRAConfig, LoRALinear, PeftTargetConfig, get_adapter_parameters
+
+    model = _Toy()
+    PeftTargetConfig(include_keys=["layer1", "child_1", "last_layer"], config=LoRAConfig(rank=4, dtype="float32")).replace_to_peft_layer(
+        model, freeze_base=True)
+    assert isinstance(model.layer1[0], LoRALinear) and isinstance(model.child["child_1"], LoRALinear)
+    assert isinstance(model.child["child_2"], nn.Linear) and isinstance(model.last_layer[0], LoRALinear)
+    assert model.layer1[0].lora_down.weight.T.shape == torch.Size([10, 4])
+    assert model.layer1[0].lora_up.weight.T.shape == torch.Size([4, 10])
+    assert torch.count_nonzero(model.layer1[0].lora_up.weight) == 0  # zero-init up => adapter starts as a no-op
+    for n, p in model.named_parameters():
+        assert p.requires_grad == (".lora_down." in n or ".lora_up." in n), n
+    keys = sorted(get_adapter_parameters(model).keys())
+    assert keys == sorted(f"{m}.{s}" for m in ("layer1.0", "child.child_1", "last_layer.0")
+                          for s in ("lora_up.weight", "lora_down.weight", "alpha"))
+    assert get_adapter_parameters(model)["layer1.0.alpha"].dim() == 0
+    with pytest.raises(ValueError):
+        PeftTargetConfig(include_keys=[], config=LoRAConfig(rank=4))
+
+
+def test_sdxl_key_renaming_bit_exact(J):
+    from vision_ft_amd.models.sdxl import util
+
+    for k, want in J["sdxl_keys"]["comfy"]:
+        assert util.convert_to_comfy_key(k) == want
+    for k, want in J["sdxl_keys"]["from_original"]:
+        assert util.denoiser_convert_from_original_key(k) == want
+    for k, want in J["sdxl_keys"]["to_original"]:
+        assert util.denoiser_convert_to_original_key(k) == want
+
+
+def test_index_helpers_bit_exact(J):
+    from vision_ft_amd.models.auraflow import Denoiser as Aura
+    from vision_ft_amd.models.auraflow import DenoiserConfig as AuraCfg
+    from vision_ft_amd.models.lumina2 import Denoiser as Lum
+    from vision_ft_amd.models.lumina2 import DenoiserConfig as LumCfg
+
+    with torch.device("meta"):
+        lum = Lum(LumCfg(hidden_dim=256, num_heads=4, num_kv_heads=2, depth=1, refiner_depth=1, in_channels=8, out_channels=8,
+                         caption_dim=48, axes_dims=[16, 24, 24], axes_lens=[64, 32, 32]))
+        aura = Aura(AuraCfg(num_attention_heads=2, attention_head_dim=64, caption_projection_dim=128, num_double_layers=1,
+                            num_single_layers=1, joint_attention_dim=32, pos_embed_max_size=256))
+    for rec in J["position_ids"]:
+        assert lum.get_position_ids(*rec["args"]).tolist() == rec["ids"]
+    for rec in J["aura_pe_index"]:
+        assert aura.pe_selection_index_based_on_dim(*rec["hw"]).tolist() == rec["idx"]
+    x = torch.arange(2 * 4 * 4 * 6, dtype=torch.float32).view(2, 4, 4, 6)
+    assert aura.patchify(x).tolist() == J["aura_patchify"]
+    assert aura.unpatchify(aura.patchify(x), 2, 3).tolist() == J["aura_unpatchify"]
+    xl = torch.arange(8 * 4 * 6, dtype=torch.float32).view(8, 4, 6)
+    assert lum.patchify(xl).tolist() == J["lumina_patchify"]
+    assert torch.equal(lum.unpatchify(lum.patchify(xl), 4, 6, 2, 8), xl)
+
+
+# ---- config / saving -------------------------------------------------------------------------
+def test_train_config_yaml(tmp_path):
+    from vision_ft_amd.config import TrainConfig
+    from vision_ft_amd.utils.state_dict import RegexMatch
+
+    for p in ("configs/sdxl/text_to_image_lora.yml", "configs/auraflow/lora.yml", "configs/lumina2/lora.yml"):
+        cfg = TrainConfig.from_config_file(p)
+        assert cfg.peft is not None and cfg.optimizer.name == "torch.optim.AdamW" and cfg.seed == 42
+    aura = TrainConfig.from_config_file("configs/auraflow/lora.yml")
+    assert isinstance(aura.peft.include_keys[0], RegexMatch)
+    bad = tmp_path / "bad.yml"
+    bad.write_text("model: {}\ndataset: {}\nseed: 'x'\n")
+    with pytest.raises(Exception):
+        TrainConfig.from_config_file(str(bad))  # strict validation
+
+
+def test_saving_cadence():
+    from vision_ft_amd.saving import ModelSavingStrategy
+
+    s = ModelSavingStrategy(total_epochs=3, steps_per_epoch=10, per_epochs=1, per_steps=None, save_last=True)
+    assert [st for st in range(1, 31) if s.should_save((st + 9) // 10, st)] == [10, 20, 30]
+    assert not s.should_save(0, 0)
+    s = ModelSavingStrategy(total_epochs=1, steps_per_epoch=10, per_epochs=None, per_steps=4, save_last=True)
+    assert [st for st in range(1, 11) if s.should_save(1, st)] == [4, 8]
+    s = ModelSavingStrategy(total_epochs=1, steps_per_epoch=10, per_epochs=0.5, per_steps=None, save_last=True)
+    assert [st for st in range(1, 11) if s.should_save(1, st)] == [5, 10]
+    with pytest.raises(ValueError):
+        ModelSavingStrategy(total_epochs=1, steps_per_epoch=10, per_epochs=1.5, per_steps=None, save_last=True)
+
+
+# ---- C ABI ------------------------------------------------------------------------------------
+def test_c_abi_exports_every_declared_symbol():
+    """include/vft_hip.h is the contract: every `vft_*` function declared there must be exported by
+    the built library and bound in vision_ft_amd/_C.py (no compute calls here)."""
+    from vision_ft_amd import _C
+
+    header = open("include/vft_hip.h").read()
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(vft_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 20
+    lib = _C.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vft_hip.h but not exported"
+    assert declared == set(_C.SIGNATURES), declared ^ set(_C.SIGNATURES)
+    assert lib.vft_version() >= 100
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    import ctypes
+
+    from vision_ft_amd import _C
+
+    lib = _C.lib()
+    z = ctypes.c_void_p(0)
+    st = lib.vft_attn_fwd(z, z, z, z, z, z, 1, 3, 2, 8, 8, 64, _C.i64x3((0, 0, 0)), _C.i64x3((0, 0, 0)), _C.i64x3((0, 0, 0)),
+                          _C.i64x3((0, 0, 0)), 1.0, z)
+    assert st == 1 and b"Hq" in lib.vft_last_error()
+    st = lib.vft_geglu_fwd(z, z, 4, 7, z)
+    assert st == 1
+    with pytest.raises(ValueError):
+        _C.check(st, "vft_geglu_fwd")
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from vision_ft_amd import kernels
+    from vision_ft_amd.models.sdxl import Denoiser, DenoiserConfig
+
+    x = torch.randn(2, 8, 64, dtype=torch.bfloat16)
+    for fn in (lambda: kernels.layer_norm(x, None, None, 1e-5), lambda: kernels.geglu(x), lambda: kernels.swiglu(x, x),
+               lambda: kernels.flash_attention(x[None], x[None], x[None])):
+        with pytest.raises(RuntimeError):
+            fn()
+    m = Denoiser(DenoiserConfig(hidden_dim=64, block_out_channels=[64, 128, 128], context_dim=64)).to(torch.bfloat16)
+    with pytest.raises(RuntimeError):  # the product path has no CPU fallback
+        m(latents=torch.randn(1, 4, 16, 16), timestep=torch.tensor([1]), encoder_hidden_states=torch.randn(1, 7, 64),
+          encoder_pooler_output=torch.randn(1, 1280), original_size=torch.tensor([[64, 64]]),
+          target_size=torch.tensor([[64, 64]]), crop_coords_top_left=torch.tensor([[0, 0]]))
+
+
+def test_product_never_imports_oracle():
+    import pathlib
+
+    for path in pathlib.Path("vision_ft_amd").rglob("*.py"):
+        src = path.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+    for path in list(pathlib.Path("train").rglob("*.py")):
+        assert "oracle" not in path.read_text(), path

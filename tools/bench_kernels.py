@@ -1,0 +1,94 @@
+"""Micro-benchmarks of the hand-written kernels at the headline shapes (run on the GPU box):
+   python tools/bench_kernels.py [lora|attn|norm|all]
+Prints achieved GB/s (HBM-bound kernels, algorithmic bytes) or TFLOP/s (attention)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from vision_ft_amd import kernels  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters * 1e-3
+
+
+def bf(*s):
+    return torch.randn(*s, device=dev, dtype=torch.float32).to(torch.bfloat16)
+
+
+def lora():
+    print("== LoRA (bytes = algorithmic, see csrc/lora.hip) ==")
+    for M, K, N, r in [(4096, 1280, 1280, 4), (4096, 1280, 10240, 4), (4096, 5120, 1280, 4), (16384, 640, 640, 4),
+                       (16384, 640, 5120, 4), (16384, 2560, 640, 4), (308, 2048, 1280, 4), (8720, 3072, 3072, 16),
+                       (8720, 3072, 8192, 16)]:
+        x, y, dy, dx = bf(M, K), bf(M, N), bf(M, N), bf(M, K)
+        A, B = bf(r, K), bf(N, r)
+        t, Bt = kernels._lora_fwd_(x, y, A, B, 0.25)
+        u = kernels._lora_bwd_dx_(dy, dx, Bt, A, 0.25)
+        tf = timeit(lambda: kernels._lora_fwd_(x, y, A, B, 0.25))
+        tb = timeit(lambda: kernels._lora_bwd_dx_(dy, dx, Bt, A, 0.25))
+        tw = timeit(lambda: kernels._lora_wgrad2(x, u, dy, t, A, B, 0.25))
+        bfwd, bbwd, bwg = 2 * M * K + 4 * M * N, 2 * M * N + 4 * M * K, 2 * M * (K + N)
+        print(f"M={M:6d} K={K:5d} N={N:5d} r={r:2d} | fwd {tf*1e6:7.1f} us {bfwd/tf/1e9:7.0f} GB/s | bwd_dx {tb*1e6:7.1f} us "
+              f"{bbwd/tb/1e9:7.0f} GB/s | wgrad2 {tw*1e6:7.1f} us {bwg/tw/1e9:7.0f} GB/s")
+
+
+def attn():
+    print("== attention (TFLOP/s: fwd 4BHSSD, bwd algorithmic 10BHSSD) ==")
+    for B, H, Hkv, Sq, Sk, D in [(4, 10, 10, 4096, 4096, 64), (4, 20, 20, 1024, 1024, 64), (4, 10, 10, 4096, 77, 64),
+                                 (4, 20, 20, 1024, 77, 64), (2, 12, 12, 4360, 4360, 256), (2, 24, 8, 4352, 4352, 96),
+                                 (16, 16, 16, 2048, 2048, 128)]:
+        q = bf(B, Sq, H, D).permute(0, 2, 1, 3).requires_grad_(True)
+        k = bf(B, Sk, Hkv, D).permute(0, 2, 1, 3).requires_grad_(True)
+        v = bf(B, Sk, Hkv, D).permute(0, 2, 1, 3).requires_grad_(True)
+        o = kernels.flash_attention(q, k, v)
+        do = bf(B, Sq, H, D).permute(0, 2, 1, 3)
+        tf = timeit(lambda: kernels.flash_attention(q, k, v))
+
+        def fb():
+            kernels.flash_attention(q, k, v).backward(do)
+
+        tfb = timeit(fb)
+        fl = 4.0 * B * H * Sq * Sk * D
+        print(f"B={B} H={H}/{Hkv} Sq={Sq} Sk={Sk} D={D:3d} | fwd {tf*1e6:8.1f} us {fl/tf/1e12:7.1f} TF/s | bwd {(tfb-tf)*1e6:8.1f} us "
+              f"{2.5*fl/(tfb-tf)/1e12:7.1f} TF/s")
+
+
+def norm():
+    print("== norms / activations (GB/s, algorithmic bytes) ==")
+    for rows, C in [(16384, 640), (4096, 1280), (8720, 3072), (8704, 2304)]:
+        x, w, b = bf(rows, C), bf(C), bf(C)
+        tf = timeit(lambda: kernels.layer_norm(x, w, b, 1e-5))
+        print(f"layer_norm rows={rows} C={C}: {tf*1e6:7.1f} us {4*rows*C/tf/1e9:7.0f} GB/s")
+    for N, C, H, W in [(4, 320, 128, 128), (4, 640, 64, 64), (4, 1280, 32, 32), (4, 1920, 64, 64)]:
+        x, w, b = bf(N, C, H, W), bf(C), bf(C)
+        tf = timeit(lambda: kernels.group_norm(x, w, b, 32, 1e-5, True))
+        print(f"group_norm+silu {N}x{C}x{H}x{W}: {tf*1e6:7.1f} us {6*x.numel()/tf/1e9:7.0f} GB/s")
+    for M, F in [(16384, 2560), (4096, 5120)]:
+        p = bf(M, 2 * F)
+        tf = timeit(lambda: kernels.geglu(p))
+        print(f"geglu M={M} F={F}: {tf*1e6:7.1f} us {6*M*F/tf/1e9:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("lora", "all"):
+        lora()
+    if which in ("attn", "all"):
+        attn()
+    if which in ("norm", "all"):
+        norm()

@@ -13,19 +13,34 @@
 
 namespace {
 
-__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
-    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+// V-wide (V = 8, 4, 2, 1 elements) loads/stores: V is the largest power of two dividing H*W, so a
+// vector never straddles two (n, c) planes
+template <int V>
+__device__ __forceinline__ void ldv(const bf16_t* p, float (&v)[V]) {
+    typedef __attribute__((ext_vector_type(V))) __bf16 vec_t;
+    if constexpr (V == 1) {
+        v[0] = (float)p[0];
+    } else {
+        vec_t t = *reinterpret_cast<const vec_t*>(p);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+        for (int i = 0; i < V; ++i) v[i] = (float)t[i];
+    }
 }
-__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
-    bf16x8 t;
+template <int V>
+__device__ __forceinline__ void stv(bf16_t* p, const float (&v)[V]) {
+    typedef __attribute__((ext_vector_type(V))) __bf16 vec_t;
+    if constexpr (V == 1) {
+        p[0] = (bf16_t)v[0];
+    } else {
+        vec_t t;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
-    *reinterpret_cast<bf16x8*>(p) = t;
+        for (int i = 0; i < V; ++i) t[i] = (bf16_t)v[i];
+        *reinterpret_cast<vec_t*>(p) = t;
+    }
 }
 
 // stats[(n*G+g)*2 + {0,1}] += (Σx, Σx²) of plane (n, c)
+template <int V>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int C,
                                                        int HW, int cpg) {
     __shared__ float red[4];
@@ -33,11 +48,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     const int n = plane / C, c = plane % C;
     const bf16_t* xp = x + (int64_t)plane * HW;
     float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x * 8; e < HW; e += 256 * 8) {
-        float v[8];
-        ld8(xp + e, v);
+    for (int e = threadIdx.x * V; e < HW; e += 256 * V) {
+        float v[V];
+        ldv<V>(xp + e, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < V; ++i) {
             s1 += v[i];
             s2 += v[i] * v[i];
         }
@@ -52,6 +67,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                        bf16_t* __restrict__ y, int C, int HW, int cpg, float eps,
@@ -59,7 +75,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const int G = C / cpg;
     const float invL = 1.f / ((float)cpg * (float)HW);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
-        const int64_t idx = e * 8;
+        const int64_t idx = e * V;
         const int64_t plane = idx / HW;
         const int c = (int)(plane % C);
         const int64_t n = plane / C;
@@ -68,19 +84,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         const float rstd = rsqrtf(fmaxf(st[1] * invL - mean * mean, 0.f) + eps);
         const float wc = w ? (float)w[c] : 1.f, bc = b ? (float)b[c] : 0.f;
         const float a = rstd * wc, o = bc - mean * a;
-        float v[8];
-        ld8(x + idx, v);
+        float v[V];
+        ldv<V>(x + idx, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < V; ++i) {
             const float z = v[i] * a + o;
             v[i] = silu ? silu_f(z) : z;
         }
-        st8(y + idx, v);
+        stv<V>(y + idx, v);
     }
 }
 
 // bstats[(n*G+g)*2 + {0,1}] += (Σ g, Σ g·xhat), g = dz·w_c, dz = dy·silu'(z) (or dy);
 // optionally dw[c] += Σ dz·xhat, db[c] += Σ dz
+template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ stats, const bf16_t* __restrict__ w,
                                                            const bf16_t* __restrict__ b, float* __restrict__ bstats,
@@ -98,12 +115,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
     const bf16_t* xp = x + (int64_t)plane * HW;
     const bf16_t* dp = dy + (int64_t)plane * HW;
     float sz = 0.f, szx = 0.f;
-    for (int e = threadIdx.x * 8; e < HW; e += 256 * 8) {
-        float v[8], d[8];
-        ld8(xp + e, v);
-        ld8(dp + e, d);
+    for (int e = threadIdx.x * V; e < HW; e += 256 * V) {
+        float v[V], d[V];
+        ldv<V>(xp + e, v);
+        ldv<V>(dp + e, d);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < V; ++i) {
             const float xh = (v[i] - mean) * rstd;
             float dz = d[i];
             if (silu) dz *= dsilu_f(xh * wc + bc);
@@ -122,6 +139,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                         const float* __restrict__ stats, const float* __restrict__ bstats,
                                                         const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const bf16_t* __restrict
     const int G = C / cpg;
     const float invL = 1.f / ((float)cpg * (float)HW);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
-        const int64_t idx = e * 8;
+        const int64_t idx = e * V;
         const int64_t plane = idx / HW;
         const int c = (int)(plane % C);
         const int64_t n = plane / C;
@@ -139,17 +157,17 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const bf16_t* __restrict
         const float rstd = rsqrtf(fmaxf(stats[row * 2 + 1] * invL - mean * mean, 0.f) + eps);
         const float mg = bstats[row * 2] * invL, mgx = bstats[row * 2 + 1] * invL;
         const float wc = w ? (float)w[c] : 1.f, bc = b ? (float)b[c] : 0.f;
-        float v[8], d[8];
-        ld8(x + idx, v);
-        ld8(dy + idx, d);
+        float v[V], d[V];
+        ldv<V>(x + idx, v);
+        ldv<V>(dy + idx, d);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < V; ++i) {
             const float xh = (v[i] - mean) * rstd;
             float dz = d[i];
             if (silu) dz *= dsilu_f(xh * wc + bc);
             v[i] = rstd * (dz * wc - mg - xh * mgx);
         }
-        st8(dx + idx, v);
+        stv<V>(dx + idx, v);
     }
 }
 
@@ -158,9 +176,14 @@ unsigned grid_for(int64_t nvec) {
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+int vec_width(int HW, const void* a, const void* b) {
+    int V = 8;
+    while (V > 1 && (HW % V != 0 || ((uintptr_t)a & (2 * V - 1)) != 0 || ((uintptr_t)b & (2 * V - 1)) != 0)) V >>= 1;
+    return V;
+}
+
 int gn_args(const char* name, int N, int C, int HW, int G) {
     VFT_CHECK_ARG(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0, "%s: bad shape N=%d C=%d HW=%d G=%d", name, N, C, HW, G);
-    VFT_CHECK_ARG(HW % 8 == 0, "%s: H*W=%d must be a multiple of 8", name, HW);
     return 0;
 }
 
@@ -173,12 +196,22 @@ extern "C" int vft_groupnorm_fwd(const void* x, void* y, const void* weight, con
     if (gn_args("vft_groupnorm_fwd", N, C, HW, G)) return 1;
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(float), st);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, stats, C, HW, C / G);
-    VFT_CHECK_LAUNCH("vft_groupnorm_fwd(stats)");
-    const int64_t nvec = (int64_t)N * C * HW / 8;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, stats,
-                       (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)y, C, HW, C / G, eps, fuse_silu, nvec);
-    VFT_CHECK_LAUNCH("vft_groupnorm_fwd(apply)");
+    const int V = vec_width(HW, x, y);
+#define VFT_GN_FWD(VV)                                                                                                  \
+    {                                                                                                                   \
+        hipLaunchKernelGGL(gn_stats_kernel<VV>, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, stats, C, HW, C / G);  \
+        const int64_t nvec = (int64_t)N * C * HW / VV;                                                                  \
+        hipLaunchKernelGGL(gn_apply_kernel<VV>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, stats,        \
+                           (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)y, C, HW, C / G, eps, fuse_silu, nvec); \
+    }
+    switch (V) {
+        case 8: VFT_GN_FWD(8); break;
+        case 4: VFT_GN_FWD(4); break;
+        case 2: VFT_GN_FWD(2); break;
+        default: VFT_GN_FWD(1); break;
+    }
+#undef VFT_GN_FWD
+    VFT_CHECK_LAUNCH("vft_groupnorm_fwd");
     return 0;
 }
 
@@ -192,13 +225,25 @@ extern "C" int vft_groupnorm_bwd(const void* x, const void* dy, const float* sta
     hipMemsetAsync(bstats, 0, (size_t)N * G * 2 * sizeof(float), st);
     if (dweight) hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
     if (dbias) hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats,
-                       (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, C, HW, C / G, eps, fuse_silu);
-    VFT_CHECK_LAUNCH("vft_groupnorm_bwd(stats)");
-    const int64_t nvec = (int64_t)N * C * HW / 8;
-    hipLaunchKernelGGL(gn_bwd_dx_kernel, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       stats, bstats, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, C, HW, C / G, eps,
-                       fuse_silu, nvec);
-    VFT_CHECK_LAUNCH("vft_groupnorm_bwd(dx)");
+    int V = vec_width(HW, x, dy);
+    if (((uintptr_t)dx & (2 * V - 1)) != 0) V = 1;
+#define VFT_GN_BWD(VV)                                                                                                    \
+    {                                                                                                                     \
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<VV>, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,   \
+                           stats, (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, C, HW, C / G, eps,  \
+                           fuse_silu);                                                                                    \
+        const int64_t nvec = (int64_t)N * C * HW / VV;                                                                    \
+        hipLaunchKernelGGL(gn_bwd_dx_kernel<VV>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x,                \
+                           (const bf16_t*)dy, stats, bstats, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, C,  \
+                           HW, C / G, eps, fuse_silu, nvec);                                                              \
+    }
+    switch (V) {
+        case 8: VFT_GN_BWD(8); break;
+        case 4: VFT_GN_BWD(4); break;
+        case 2: VFT_GN_BWD(2); break;
+        default: VFT_GN_BWD(1); break;
+    }
+#undef VFT_GN_BWD
+    VFT_CHECK_LAUNCH("vft_groupnorm_bwd");
     return 0;
 }

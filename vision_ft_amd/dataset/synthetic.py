@@ -56,7 +56,8 @@ class _Tagged(data.Dataset):
 
     def __getitem__(self, idx: int) -> dict:
         seeds = self.inner[idx]
-        return {"width": self.width, "height": self.height, "seeds": list(map(int, seeds))}
+        # every value is a list so the bucketing collate (list concatenation) applies, as for the reference's items
+        return {"width": [self.width], "height": [self.height], "seeds": list(map(int, seeds))}
 
 
 def make_latents(width: int, height: int, batch: int, channels: int, device, seed: int, dtype=torch.bfloat16,

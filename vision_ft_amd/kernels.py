@@ -349,8 +349,6 @@ def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: boo
     """GroupNorm over NCHW (fp32 statistics) with optional fused SiLU."""
     _ready(x)
     _require_gpu(x)
-    if (x.shape[2] * x.shape[3]) % 8 != 0:
-        raise ValueError("group_norm: H*W must be a multiple of 8")
     return _GroupNorm.apply(x, weight, bias, groups, eps, silu)
 
 

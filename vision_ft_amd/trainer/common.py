@@ -1,0 +1,213 @@
+"""Training loop (reference: src/trainer/common.py:31-469) without accelerate: one process per GPU,
+gradients exchanged by ``DataParallelGrads`` (flat buffer, RCCL on a side stream), step optionally
+replayed from HIP graphs.  Hook order, loss/accumulation scaling (:355-365), debug modes (:241-244,
+:324-325, :440-446), checkpoint cadence and file naming follow the reference."""
+from __future__ import annotations
+
+import importlib
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..config import DEBUG_MODE_TYPE, TrainConfig
+from ..dataloader import get_dataloader_for_bucketing
+from ..dataset.util import DatasetConfig
+from ..models.for_training import ModelForTraining, Runtime
+from ..modules.peft import print_trainable_parameters
+from ..saving import ModelSavingStrategy, get_saving_callback
+from .dp import DataParallelGrads, shard_indices
+
+
+def get_optimizer(optimizer_name: str, params, **kwargs) -> torch.optim.Optimizer:
+    """"pkg.mod.Class" string -> optimizer (reference: src/optimizer/util.py:6-31)."""
+    module_name, class_name = optimizer_name.rsplit(".", 1) if "." in optimizer_name else ("torch.optim", optimizer_name)
+    try:
+        cls = getattr(importlib.import_module(module_name), class_name)
+    except (ImportError, AttributeError) as e:
+        raise ValueError(f"Optimizer {class_name} not found in module {module_name}") from e
+    lr = kwargs.pop("lr", None)
+    assert lr is not None, "Learning rate must be provided"
+    return cls(params, lr=lr, **kwargs)
+
+
+def get_scheduler(optimizer, scheduler_name: str, **kwargs):
+    module_name, class_name = scheduler_name.rsplit(".", 1) if "." in scheduler_name else ("torch.optim.lr_scheduler", scheduler_name)
+    try:
+        cls = getattr(importlib.import_module(module_name), class_name)
+    except (ImportError, AttributeError) as e:
+        raise ValueError(f"Scheduler {class_name} not found in module {module_name}") from e
+    return cls(optimizer, **kwargs)
+
+
+def set_seed(seed: int) -> None:
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def init_distributed() -> None:
+    """torchrun / torch.distributed.run environment -> RCCL process group on this rank's GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+
+
+class Trainer:
+    def __init__(self, config: TrainConfig, seed: int | None = None) -> None:
+        init_distributed()
+        self.config = config
+        self.peft_config = config.peft
+        self.seed = config.seed if seed is None else seed
+        self.debug_mode: DEBUG_MODE_TYPE = config.trainer.debug_mode
+        self.gradient_accumulation_steps = config.trainer.gradient_accumulation_steps
+        self.accelerator = Runtime()
+        self.losses: list[float] = []
+
+    def register_model_class(self, model_cls, *args, **kwargs) -> None:
+        self.model_cls = model_cls
+        self.model: ModelForTraining = model_cls(self.accelerator, self.config, *args, **kwargs)
+
+    def register_train_dataset_class(self, dataset_config_class: type[DatasetConfig], *args, **kwargs) -> None:
+        self.dataset_config = dataset_config_class.model_validate(self.config.dataset)
+
+    def register_preview_dataset_class(self, dataset_config_class, *args, **kwargs) -> None:
+        pass  # previews are outside the hot path
+
+    @property
+    def raw_model(self) -> ModelForTraining:
+        return self.model
+
+    def print(self, *a, **k) -> None:
+        self.accelerator.print(*a, **k)
+
+    def prepare_dataloaders(self) -> None:
+        ds = self.dataset_config.get_dataset()
+        rt = self.accelerator
+        if rt.world > 1:  # rank r takes batches r, r+W, ... of the (seeded) order
+            ds = torch.utils.data.Subset(ds, shard_indices(len(ds), rt.rank, rt.world))
+        g = torch.Generator().manual_seed(self.seed)
+        self.train_dataloader = get_dataloader_for_bucketing(ds, shuffle=self.dataset_config.shuffle, num_workers=0, generator=g)
+
+    def prepare_saving_strategy(self) -> None:
+        steps = len(self.train_dataloader)
+        if (saving := self.config.saving) is not None:
+            self.saving_strategy = ModelSavingStrategy.from_config(saving.strategy, self.config.num_train_epochs, steps)
+            self.saving_callbacks = [get_saving_callback(c) for c in saving.callbacks]
+        else:
+            self.saving_strategy = ModelSavingStrategy(self.config.num_train_epochs, steps, None, None, False)
+            self.saving_callbacks = []
+
+    def setup_peft_if_needed(self) -> None:
+        if self.peft_config is None:
+            self.model._set_is_peft(False)
+            return
+        self.model._set_is_peft(True)
+        cfgs = self.peft_config if isinstance(self.peft_config, list) else [self.peft_config]
+        self.model.requires_grad_(False)  # freeze the base before wrapping (reference :179-180)
+        for c in cfgs:
+            c.replace_to_peft_layer(self.model)
+        self.model.load_peft_weights()
+
+    def prepare_model(self) -> None:
+        self.model.before_setup_model()
+        self.model.setup_model()
+        self.setup_peft_if_needed()
+        self.model.after_setup_model()
+        print_trainable_parameters(self.model, self.print)
+
+    def prepare_optimizer(self) -> None:
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.dp = DataParallelGrads(params)
+        args = dict(self.config.optimizer.args)
+        if self.config.trainer.hip_graph and self.config.optimizer.name.endswith("AdamW") and torch.cuda.is_available():
+            args.setdefault("capturable", True)
+            args.setdefault("fused", True)
+        self.optimizer = get_optimizer(self.config.optimizer.name, params, **args)
+        sc = self.config.scheduler
+        self.scheduler = get_scheduler(self.optimizer, sc.name, **sc.args) if sc is not None else None
+
+    def before_train(self) -> None:
+        if self.config.trainer.fp32_matmul_precision is not None:
+            torch.set_float32_matmul_precision(self.config.trainer.fp32_matmul_precision)
+        set_seed(self.seed)
+        self.prepare_dataloaders()
+        self.prepare_saving_strategy()
+        if self.debug_mode == "dataset":
+            for batch in self.train_dataloader:
+                self.print(batch)
+            return
+        self.prepare_model()
+        self.prepare_optimizer()
+
+    def backward(self, loss: torch.Tensor) -> None:
+        self.raw_model.before_backward()
+        (loss / self.gradient_accumulation_steps).backward()
+        self.raw_model.after_backward()
+
+    def apply_gradients(self, current_step: int) -> None:
+        if current_step % self.gradient_accumulation_steps == 0:
+            self.dp.reduce_async()  # skipped on non-boundary micro-steps == the reference's no_sync (:301-308)
+            self.dp.wait()
+            self.optimizer.step()
+            if self.scheduler is not None:
+                self.scheduler.step()
+            self.dp.zero_grad()
+
+    def call_saving_callbacks(self, epoch: int, steps: int) -> None:
+        if not self.saving_strategy.should_save(epoch, steps):
+            return
+        self.accelerator.wait_for_everyone()
+        if self.saving_callbacks and self.accelerator.is_main_process:
+            sd, meta = self.raw_model.get_state_dict_to_save(), self.raw_model.get_metadata_to_save()
+            for cb in self.saving_callbacks:
+                cb.save_state_dict(sd, epoch, steps, metadata=meta)
+        self.accelerator.wait_for_everyone()
+
+    def training_loop(self) -> None:
+        step = 0
+        graphs: dict = {}
+        use_graph = (self.config.trainer.hip_graph and torch.cuda.is_available() and self.gradient_accumulation_steps == 1
+                     and getattr(self.raw_model, "graph_safe", False))
+        for epoch in range(1, self.config.num_train_epochs + 1):
+            self.raw_model.before_train_epoch()
+            for batch in self.train_dataloader:
+                step += 1
+                self.raw_model.before_train_step()
+                if use_graph:
+                    key = self.raw_model.stage_batch(batch)  # copies the batch into static tensors
+                    if key not in graphs:
+                        from .graph import GraphedTrainStep
+
+                        graphs[key] = GraphedTrainStep(self.raw_model.train_step_static, self.optimizer, self.dp,
+                                                       after_backward=self.raw_model.after_backward)
+                    loss = graphs[key]()
+                    if self.scheduler is not None:
+                        self.scheduler.step()
+                else:
+                    loss = self.model(batch)
+                    self.backward(loss)
+                    self.apply_gradients(step)
+                if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
+                    self.losses.append(float(loss.detach()))
+                self.call_saving_callbacks(epoch, step)
+                self.raw_model.after_train_step()
+                if self.debug_mode == "1step":
+                    break
+            self.raw_model.after_train_epoch()
+            if self.debug_mode == "1step":
+                break
+
+    def train(self) -> None:
+        self.before_train()
+        if self.debug_mode == "dataset":
+            return
+        self.raw_model.sanity_check()
+        if self.debug_mode == "sanity_check":
+            self.print("Sanity check done. Exiting...")
+            return
+        self.training_loop()

@@ -1,0 +1,95 @@
+"""Shared base of the three text-to-image training tasks (train/*/text_to_image.py).
+
+The reference tasks (train/sdxl/text_to_image.py:28-210 etc.) encode captions and images with the
+frozen text encoders / VAE inside ``train_step``; those are out of the hot path (SURVEY.md §2 rows
+19-20), so a batch here already carries latents and text embeddings — drawn synthetically, per
+aspect-ratio bucket, by ``SyntheticLatentDatasetConfig`` — and everything from the timestep draw on
+is the reference's step.  Batches are staged into static device tensors per bucket shape so the
+step can be replayed from a HIP graph."""
+from __future__ import annotations
+
+import torch
+from safetensors.torch import load_file
+
+from ..dataset.synthetic import make_latents
+from ..models.for_training import ModelForTraining
+from ..modules.peft import get_adapter_parameters
+from ..utils.dtype import str_to_dtype
+
+
+class DenoiserTask(ModelForTraining):
+    graph_safe = True
+    latent_channels = 4
+    tensor_prefix = ""  # checkpoint key prefix of the denoiser weights
+
+    def build_denoiser(self) -> torch.nn.Module:
+        raise NotImplementedError
+
+    def make_conditions(self, batch: int, width: int, height: int, seed: int) -> dict[str, torch.Tensor]:
+        raise NotImplementedError
+
+    def denoise_loss(self, latents: torch.Tensor, cond: dict[str, torch.Tensor]) -> torch.Tensor:
+        raise NotImplementedError
+
+    # ---- ModelForTraining protocol -----------------------------------------------------------
+    def setup_model(self) -> None:
+        dev = self.accelerator.device
+        dtype = str_to_dtype(self.model_config.dtype)
+        with torch.device(dev):
+            self.model = self.build_denoiser()
+        self.model.to(dtype)
+        path = self.model_config.checkpoint_path
+        if path not in ("", "random", None):
+            sd = load_file(path)
+            pre = self.tensor_prefix
+            sd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)} if pre and any(k.startswith(pre) for k in sd) else sd
+            self.model.load_state_dict(sd, strict=True)
+        self._static: dict = {}
+
+    def after_setup_model(self) -> None:
+        if self.config.trainer.gradient_checkpointing:
+            for name in ("set_gradient_checkpointing", "_set_gradient_checkpointing"):
+                if hasattr(self.model, name):
+                    getattr(self.model, name)(True)
+        super().after_setup_model()
+
+    def sanity_check(self) -> None:
+        with torch.no_grad():
+            cond = self.make_conditions(1, 768, 768, seed=0)
+            lat = make_latents(768, 768, 1, self.latent_channels, self.accelerator.device, seed=0)
+            self.denoise_loss(lat, cond)
+
+    def stage_batch(self, batch: dict) -> tuple:
+        """Materialise the batch on the device into per-shape static tensors; returns the graph key."""
+        w, h, seeds = batch["width"], batch["height"], batch["seeds"]
+        w, h = (int(w[0]) if isinstance(w, (list, tuple)) else int(w)), (int(h[0]) if isinstance(h, (list, tuple)) else int(h))
+        key = (w, h, len(seeds))
+        lat = make_latents(w, h, len(seeds), self.latent_channels, self.accelerator.device, seed=int(seeds[0]))
+        cond = self.make_conditions(len(seeds), w, h, seed=int(seeds[0]))
+        if key not in self._static:
+            self._static[key] = (lat, cond)
+        else:
+            s_lat, s_cond = self._static[key]
+            s_lat.copy_(lat)
+            for k, v in cond.items():
+                s_cond[k].copy_(v)
+        self._key = key
+        return key
+
+    def train_step_static(self) -> torch.Tensor:
+        lat, cond = self._static[self._key]
+        loss = self.denoise_loss(lat, cond)
+        self.log("train/loss", loss, on_step=True, on_epoch=True)
+        return loss
+
+    def train_step(self, batch: dict) -> torch.Tensor:
+        self.stage_batch(batch)
+        return self.train_step_static()
+
+    def get_state_dict_to_save(self) -> dict[str, torch.Tensor]:
+        if not self._is_peft:
+            return self.model.state_dict()
+        return {self.convert_adapter_key(k): v for k, v in get_adapter_parameters(self.model).items()}
+
+    def convert_adapter_key(self, key: str) -> str:
+        return key
