@@ -137,11 +137,21 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------------------------------------
 // wgrad stage 1: P[mb][k][j] = Σ_{m in 256-row block mb} X[m][k] · T[m][j]     (fp32, r <= 32)
 // Gᵀ tile (32 k x 32 j) per MFMA: A = Xᵀ via ds_read_b64_tr_b16 of the row-major staged X tile,
-// B = T rows gathered in the accumulator-k order.  block = 4 waves; 64 rows per iteration, 16 per
-// wave; K tile = 128 columns.  Waves are reduced through LDS, so one partial per block.
+// B = T rows (staged in LDS) in the accumulator-k order.  block = 4 waves; 64-row slabs, each wave
+// owns 32 of the tile's 128 columns; the next slab is fetched into registers under the MFMAs.
 // blockIdx.z selects the problem (0: X=x,T=u -> dA ; 1: X=dy,T=t -> dB).
 // ---------------------------------------------------------------------------------------------
-constexpr int WG_ROWS = 256, WG_COLS = 128, WG_LD = WG_COLS + 8;
+constexpr int WG_COLS = 128, WG_LD = WG_COLS + 8;
+
+// rows of X each workgroup reduces: large enough that few partials are written, small enough that
+// (row blocks x column tiles x 2 problems) still fills 256 CUs a few times over
+__host__ inline int wgrad_rows_per_block(int M, int K, int N) {
+    const int64_t ctiles = (int64_t)(K + WG_COLS - 1) / WG_COLS + (N + WG_COLS - 1) / WG_COLS;
+    int64_t rpb = ((int64_t)M * ctiles / 1024 + 63) / 64 * 64;
+    if (rpb < 256) rpb = 256;
+    if (rpb > 4096) rpb = 4096;
+    return (int)rpb;
+}
 
 struct WgradProblem {
     const bf16_t* x;
@@ -162,10 +172,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0, 
     return __builtin_bit_cast(bf16x8, both);
 }
 
-__global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r) {
+__global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r,
+                                                                 int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);                    // [64][WG_LD]
-    float* Red = reinterpret_cast<float*>(smem + 64 * WG_LD * 2);    // [3][4][16][64]
+    bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);                 // [64][WG_LD]
+    bf16_t* Ts = reinterpret_cast<bf16_t*>(smem + 64 * WG_LD * 2);  // [64][r]
     const WgradProblem& p = blockIdx.z == 0 ? p0 : p1;
     const int K = p.K;
     const int k0 = blockIdx.x * WG_COLS;
@@ -175,59 +186,64 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0
     const int64_t ldx = p.ldx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, j = lane & 31;
     const int mb = blockIdx.y;
-    const int mstart = mb * WG_ROWS;
-    f32x16 acc[4];
+    const int mstart = mb * rows_per_block;
+    const int mend = min(M, mstart + rows_per_block);
+    const int tvecs = 64 * r / 8;  // 16-byte vectors in one 64-row slab of T
+    f32x16 acc;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    for (int it = 0; it < WG_ROWS / 64; ++it) {
-        const int r0 = mstart + it * 64;
-        if (r0 >= M) break;
-        __syncthreads();
+    u32x4 xr[4];
+    bf16x8 tr8 = zero8();
+    auto fetch = [&](int r0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = q * 256 + tid;
             const int row = c / 16, col = (c % 16) * 8;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r0 + row < M && k0 + col < K) v = *reinterpret_cast<const u32x4*>(x + (int64_t)(r0 + row) * ldx + k0 + col);
-            *reinterpret_cast<u32x4*>(Xs + row * WG_LD + col) = v;
+            xr[q] = u32x4{0u, 0u, 0u, 0u};
+            if (r0 + row < mend && k0 + col < K) xr[q] = *reinterpret_cast<const u32x4*>(x + (int64_t)(r0 + row) * ldx + k0 + col);
         }
+        tr8 = zero8();
+        if (tid < tvecs) {
+            const int64_t e0 = (int64_t)r0 * r + tid * 8;
+            if (e0 + 8 <= (int64_t)mend * r) {
+                tr8 = *reinterpret_cast<const bf16x8*>(t + e0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q < (int64_t)mend * r) tr8[q] = t[e0 + q];
+            }
+        }
+    };
+    if (mstart < mend) fetch(mstart);
+    for (int r0 = mstart; r0 < mend; r0 += 64) {
+        __syncthreads();  // previous slab fully consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * 256 + tid;
+            *reinterpret_cast<u32x4*>(Xs + (c / 16) * WG_LD + (c % 16) * 8) = xr[q];
+        }
+        if (tid < tvecs) *reinterpret_cast<bf16x8*>(Ts + tid * 8) = tr8;
         __syncthreads();
-        bf16x8 b = zero8();
-        if (j < r) {
+        if (r0 + 64 < mend) fetch(r0 + 64);  // next slab's loads fly under this slab's MFMAs
+        // this wave: output columns [wv*32, wv*32+32) of the tile, all 64 rows of the slab
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = r0 + wv * 16 + 8 * (i >> 2) + 4 * h + (i & 3);
-                if (m < M) b[i] = t[(int64_t)m * r + j];
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 b = zero8();
+            if (j < r) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) b[i] = Ts[(ks * 16 + 8 * (i >> 2) + 4 * h + (i & 3)) * r + j];
             }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x8 a = tr_frag(Xs, WG_LD, wv * 16, c * 32, lane);
-            acc[c] = mfma32(a, b, acc[c]);
+            bf16x8 a = tr_frag(Xs, WG_LD, ks * 16, wv * 32, lane);
+            acc = mfma32(a, b, acc);
         }
     }
-    __syncthreads();
-    if (wv > 0) {
+    if (j < r) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Red[(((wv - 1) * 4 + c) * 16 + i) * 64 + lane] = acc[c][i];
-    }
-    __syncthreads();
-    if (wv == 0 && j < r) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = acc[c][i];
-#pragma unroll
-                for (int ww = 0; ww < 3; ++ww) v += Red[((ww * 4 + c) * 16 + i) * 64 + lane];
-                const int k = k0 + c * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (k < K) p.part[((int64_t)mb * K + k) * r + j] = v;
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int k = k0 + wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (k < K) p.part[((int64_t)mb * K + k) * r + j] = acc[i];
+        }
     }
 }
 
@@ -297,7 +313,8 @@ extern "C" int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, 
 }
 
 extern "C" size_t vft_lora_wgrad_workspace(int M, int K, int N, int r) {
-    return (size_t)((M + WG_ROWS - 1) / WG_ROWS) * (size_t)(K + N) * (size_t)r * sizeof(float);
+    const int rpb = wgrad_rows_per_block(M, K, N);
+    return (size_t)((M + rpb - 1) / rpb) * (size_t)(K + N) * (size_t)r * sizeof(float);
 }
 
 extern "C" int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t, void* d_down, void* d_up,
@@ -308,20 +325,15 @@ extern "C" int vft_lora_wgrad2(const void* x, const void* u, const void* dy, con
     VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "vft_lora_wgrad2: K, N, strides must be multiples of 8");
     VFT_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "vft_lora_wgrad2: activations must be 16-byte aligned");
     VFT_CHECK_ARG(ws_bytes >= vft_lora_wgrad_workspace(M, K, N, r), "vft_lora_wgrad2: workspace too small");
-    const int nmb = (M + WG_ROWS - 1) / WG_ROWS;
+    const int rpb = wgrad_rows_per_block(M, K, N);
+    const int nmb = (M + rpb - 1) / rpb;
     WgradProblem pa{(const bf16_t*)x, (const bf16_t*)u, workspace, (bf16_t*)d_down, K, ldx, (int64_t)K, 1};  // dA (r,K)
     WgradProblem pb{(const bf16_t*)dy, (const bf16_t*)t, workspace + (size_t)nmb * K * r, (bf16_t*)d_up, N, lddy, 1,
                     (int64_t)r};  // dB (N,r)
-    constexpr size_t lds = 64 * WG_LD * 2 + 3 * 4 * 16 * 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(lora_wgrad_partial_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    const size_t lds = 64 * WG_LD * 2 + 64 * (size_t)r * 2;
     const int kmax = K > N ? K : N;
     hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, 2), dim3(256), lds,
-                       (hipStream_t)stream, pa, pb, M, r);
+                       (hipStream_t)stream, pa, pb, M, r, rpb);
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(partial)");
     const int64_t ne = (int64_t)kmax * r;
     hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 2), dim3(256), 0,
