@@ -143,6 +143,30 @@ int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void*
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,
                       int C, int rows_per_batch, int use_tanh, void* stream);
 
+/* ---- GEMM (bf16 / NF4 weight) ----------------------------------------------------------------
+ * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, weight B row-major [out,in]
+ * as nn.Linear stores it.  K % 64 == 0, N % 4 == 0.
+ * vft_gemm_nt_bf16: bf16 weight (replaces nn.Linear -> cuBLAS on the denoisers' projections).
+ * vft_gemm_nf4:     weight in the bitsandbytes NF4 layout (replaces bnb.nn.Linear4bit.forward ->
+ *                   bnb.matmul_4bit, src/modules/quant/bnb.py:37-129): packed uint8 (element 2i in the
+ *                   high nibble), blocksize 64, absmax either fp32 [nblocks] (absmax_is_u8 = 0) or
+ *                   double-quantised uint8 [nblocks] with nested_absmax fp32 [ceil(nblocks/256)],
+ *                   nested_code fp32 [256] and nested_offset; code = the 16-entry NF4 quant_map.
+ *                   The dequantisation happens inside the GEMM's staging prologue.
+ *                   transpose_w = 0:  c[M,out] = a[M,in]  . W^T (+bias)     (forward)
+ *                   transpose_w = 1:  c[M,in]  = a[M,out] . W               (data gradient)
+ * vft_nf4_dequant:  out[out,in] bf16 = dequantised weight (tests / tooling).
+ */
+int vft_gemm_nt_bf16(const void* a, const void* b, void* c, const void* bias, int M, int N, int K,
+                     int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+int vft_gemm_nf4(const void* a, void* c, const void* bias, const void* packed, const void* absmax,
+                 int absmax_is_u8, const float* nested_absmax, const float* nested_code, const float* code,
+                 float nested_offset, int out_features, int in_features, int M, int64_t lda, int64_t ldc,
+                 int transpose_w, void* stream);
+int vft_nf4_dequant(void* out, const void* packed, const void* absmax, int absmax_is_u8,
+                    const float* nested_absmax, const float* nested_code, const float* code,
+                    float nested_offset, int out_features, int in_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

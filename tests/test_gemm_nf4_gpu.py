@@ -1,0 +1,172 @@
+"""GPU parity of the MFMA GEMM and the NF4-fused linear (C ABI: vft_gemm_nt_bf16, vft_gemm_nf4,
+vft_nf4_dequant) vs fp32 PyTorch / the numpy NF4 oracle.  NF4 parity vs bitsandbytes itself is
+unpinned (oracle/nf4.py header); integer work (codes, packing, key names) is checked exactly."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nf4 as onf4
+
+from .helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(g, *s, sc=1.0):
+    return (torch.randn(*s, generator=g) * sc).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(4096, 1280, 1280, True), (1000, 640, 2048, False), (333, 5120, 640, True),
+                                        (128, 128, 64, True), (77, 132, 192, True), (1, 4, 64, False)])
+def test_gemm_nt_bf16(gpu, M, N, K, bias):
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(0)
+    x, w = _bf(g, M, K), _bf(g, N, K, sc=K**-0.5)
+    b = _bf(g, N, sc=0.2) if bias else None
+    y = kernels.gemm_nt(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu))
+    ref = x.float() @ w.float().t() + (0 if b is None else b.float())
+    assert rel_err(y.cpu(), ref) < 5e-3, rel_err(y.cpu(), ref)
+
+
+def test_gemm_strided_rows(gpu):
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(1)
+    big = _bf(g, 300, 3 * 640).to(gpu)
+    x = big[:, 640:1280]  # row stride 1920, column offset
+    w = _bf(g, 256, 640, sc=0.04).to(gpu)
+    y = kernels.gemm_nt(x, w)
+    assert rel_err(y.cpu(), x.cpu().float() @ w.cpu().float().t()) < 5e-3
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_nf4_quantize_matches_oracle_exactly(double_quant):
+    from vision_ft_amd.modules.quant import quantize_nf4
+
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(192, 256, generator=g) * 0.05
+    got = quantize_nf4(w, double_quant=double_quant)
+    want = onf4.quantize_nf4(w.numpy(), 64, double_quant)
+    assert got[""].dtype == torch.uint8 and got[""].shape == (192 * 256 // 2, 1)
+    assert np.array_equal(got[""].numpy(), want[""])  # codes + packing: bit-exact
+    assert np.array_equal(got[".quant_map"].numpy(), want[".quant_map"])
+    if double_quant:
+        assert np.array_equal(got[".absmax"].numpy(), want[".absmax"])
+        np.testing.assert_allclose(got[".nested_absmax"].numpy(), want[".nested_absmax"], rtol=1e-6)
+        np.testing.assert_allclose(got[".nested_quant_map"].numpy(), want[".nested_quant_map"], rtol=1e-6)
+    else:
+        np.testing.assert_array_equal(got[".absmax"].numpy(), want[".absmax"])
+    mg = json.loads(bytes(got[".quant_state.bitsandbytes__nf4"].tolist()).decode())
+    mw = json.loads(bytes(want[".quant_state.bitsandbytes__nf4"].tolist()).decode())
+    assert mg["quant_type"] == mw["quant_type"] == "nf4" and mg["shape"] == mw["shape"] and mg["blocksize"] == 64
+
+
+
+def _make_layer(gpu, out_f, in_f, double_quant, bias=True, seed=3):
+    from vision_ft_amd.modules.quant import NF4Linear, quantize_nf4
+
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(out_f, in_f, generator=g) * in_f**-0.5
+    q = quantize_nf4(w, double_quant=double_quant)
+    sd = {"weight" + k: v for k, v in q.items()}
+    b = None
+    if bias:
+        b = _bf(g, out_f, sc=0.1)
+        sd["bias"] = b
+    layer = NF4Linear(in_f, out_f, bias=bias)
+    layer.load_state_dict(sd, strict=True)
+    layer = layer.to(gpu)
+    wd = torch.from_numpy(onf4.dequantize_nf4({k: v.numpy() for k, v in q.items()}))  # fp32 oracle dequant
+    return layer, wd, b, sd
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_nf4_dequant_kernel_matches_oracle(gpu, double_quant):
+    layer, wd, _, _ = _make_layer(gpu, 384, 512, double_quant)
+    got = layer.dequantize().cpu()
+    assert got.shape == wd.shape
+    want = wd.to(torch.bfloat16)
+    mism = (got != want).float().mean().item()
+    assert mism < 1e-3, mism  # bf16 rounding of identical fp32 products (fma contraction may flip a last bit)
+    assert rel_err(got, wd) < 4e-3
+
+
+@pytest.mark.parametrize("M,out_f,in_f,dq", [(520, 3840, 2304, True), (333, 2304, 9216, True), (77, 256, 128, False),
+                                             (1024, 9216, 2304, False)])
+def test_nf4_linear_forward_backward(gpu, M, out_f, in_f, dq):
+    layer, wd, b, _ = _make_layer(gpu, out_f, in_f, dq)
+    g = torch.Generator().manual_seed(4)
+    x, gy = _bf(g, 2, M // 2 if M % 2 == 0 else M, in_f), None
+    x = x.reshape(-1, in_f)[:M].contiguous()
+    gy = _bf(g, M, out_f)
+    xg = x.to(gpu).requires_grad_(True)
+    y = layer(xg)
+    y.backward(gy.to(gpu))
+    wb = wd.to(torch.bfloat16).float()  # the kernel multiplies bf16-rounded dequantised weights
+    ref = x.float() @ wb.t() + b.float()
+    assert rel_err(y.cpu(), ref) < 5e-3, rel_err(y.cpu(), ref)
+    assert rel_err(xg.grad.cpu(), gy.float() @ wb) < 5e-3, rel_err(xg.grad.cpu(), gy.float() @ wb)
+
+
+def test_nf4_state_dict_layout_and_roundtrip(gpu):
+    """Mirrors the reference's tests/test_modules_quant.py:153-193: key names, uint8 storage, reload
+    self-consistency."""
+    from vision_ft_amd.modules.quant import NF4Linear, get_quant_type_from_children_dict
+
+    layer, _, _, sd_in = _make_layer(gpu, 256, 128, True)
+    sd = layer.state_dict()
+    assert sd["weight"].dtype == torch.uint8
+    assert "weight.quant_state.bitsandbytes__nf4" in sd and "weight.absmax" in sd and "weight.nested_quant_map" in sd
+    assert get_quant_type_from_children_dict({k[len("weight."):]: v for k, v in sd.items() if k.startswith("weight.")}) == "bnb_nf4"
+    clone = NF4Linear(128, 256, bias=True)
+    clone.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
+    clone = clone.to(gpu)
+    x = torch.randn(5, 128, device=gpu).to(torch.bfloat16)
+    assert torch.equal(layer(x), clone(x))
+    with pytest.raises(RuntimeError):
+        NF4Linear(128, 256).load_state_dict({"weight": torch.zeros(256, 128), "bias": torch.zeros(256)})  # not pre-quantised
+
+
+def test_qlora_tiny_lumina_step(gpu):
+    """BASELINE config 4 in miniature: NF4 base (checkpoint sniffing -> NF4Linear) + bf16 LoRA on top;
+    output close to the bf16 model's, LoRA gradients flow, base stays frozen and 4-bit."""
+    from vision_ft_amd.models.lumina2 import Denoiser, DenoiserConfig
+    from vision_ft_amd.modules.peft import LoRAConfig, PeftTargetConfig
+    from vision_ft_amd.modules.quant import NF4Linear, quantize_state_dict, replace_by_prequantized_weights
+
+    cfg = DenoiserConfig(in_channels=8, out_channels=8, hidden_dim=256, caption_dim=64, timestep_embed_dim=64, depth=2,
+                         num_heads=4, num_kv_heads=2, refiner_depth=1, multiple_of=64, axes_dims=[16, 24, 24], axes_lens=[64, 32, 32])
+    torch.manual_seed(0)
+    ref_model = Denoiser(cfg)
+    for blk in list(ref_model.layers) + list(ref_model.noise_refiner):  # zero-init AdaLN would hide everything
+        torch.nn.init.normal_(blk.adaLN_modulation[1].weight, std=0.02)
+    sd = {k: v.clone() for k, v in ref_model.state_dict().items()}
+    qsd = quantize_state_dict({k: v.clone() for k, v in sd.items()}, "bnb_nf4", ["attention.qkv.weight", "attention.out.weight", "feed_forward"],
+                              ["noise_refiner", "context_refiner"], double_quant=True)
+    qmodel = Denoiser(cfg)
+    replace_by_prequantized_weights(qmodel, qsd)
+    n_q = sum(isinstance(m, NF4Linear) for m in qmodel.modules())
+    assert n_q == 2 * 5  # qkv, out, w1, w2, w3 of the two main layers
+    qmodel.load_state_dict(qsd, strict=True)
+    ref_model, qmodel = ref_model.to(gpu, torch.bfloat16), qmodel.to(gpu, torch.bfloat16)
+    qmodel.requires_grad_(False)
+    PeftTargetConfig(include_keys=["attention", "feed_forward"], exclude_keys=["noise_refiner"],
+                     config=LoRAConfig(rank=4)).replace_to_peft_layer(qmodel)
+    g = torch.Generator(device=gpu).manual_seed(1)
+    lat = torch.randn(2, 8, 16, 24, generator=g, device=gpu).to(torch.bfloat16)
+    cap = torch.randn(2, 12, 64, generator=g, device=gpu).to(torch.bfloat16)
+    mask = torch.arange(12, device=gpu)[None] < torch.tensor([12, 7], device=gpu)[:, None]
+    t = torch.tensor([0.2, 0.7], device=gpu)
+    qmodel.train()
+    o_q = torch.nested.to_padded_tensor(qmodel(latents=lat, caption_features=cap, timestep=t, caption_mask=mask)[0], 0.0)
+    with torch.no_grad():
+        o_r = torch.nested.to_padded_tensor(ref_model(latents=lat, caption_features=cap, timestep=t, caption_mask=mask)[0], 0.0)
+    assert rel_err(o_q, o_r) < 0.15  # 4-bit weights: close to, not equal to, the bf16 model
+    o_q.float().square().mean().backward()
+    grads = [p.grad for n, p in qmodel.named_parameters() if "lora_" in n]
+    assert len(grads) == 2 * 15 and all(gr is not None and torch.isfinite(gr.float()).all() for gr in grads)
+    assert any(gr.abs().sum() > 0 for gr in grads)
+    assert all(p.grad is None for n, p in qmodel.named_parameters() if "lora_" not in n)

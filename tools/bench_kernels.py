@@ -84,6 +84,32 @@ def norm():
         print(f"geglu M={M} F={F}: {tf*1e6:7.1f} us {6*M*F/tf/1e9:7.0f} GB/s")
 
 
+def gemm():
+    import torch.nn.functional as F
+
+    print("== GEMM NT bf16: ours vs hipBLASLt (F.linear), TFLOP/s; NF4-fused forward / dgrad ==")
+    from vision_ft_amd.modules.quant import NF4Linear, quantize_nf4
+
+    for M, N, K in [(65536, 640, 640), (16384, 1280, 1280), (16384, 10240, 1280), (16384, 1280, 5120), (65536, 5120, 640),
+                    (17408, 3840, 2304), (17408, 9216, 2304), (17408, 2304, 9216), (8720, 3072, 3072), (8720, 8192, 3072)]:
+        x, w, b = bf(M, K), bf(N, K), bf(N)
+        to = timeit(lambda: kernels.gemm_nt(x, w, b), iters=10)
+        tl = timeit(lambda: F.linear(x, w, b), iters=10)
+        fl = 2.0 * M * N * K
+        line = f"M={M:6d} N={N:5d} K={K:5d} | ours {to*1e6:8.1f} us {fl/to/1e12:7.1f} TF/s | hipBLASLt {tl*1e6:8.1f} us {fl/tl/1e12:7.1f} TF/s"
+        if K % 64 == 0 and N % 64 == 0 and M <= 20000:
+            q = quantize_nf4(w.float().cpu() * 0.02, double_quant=True)
+            layer = NF4Linear(K, N, bias=False)
+            layer.load_state_dict({"weight" + k: v for k, v in q.items()})
+            layer = layer.to(dev)
+            st = layer.quant_state()
+            dy = bf(M, N)
+            tq = timeit(lambda: kernels._nf4_gemm(x, st, None, False), iters=10)
+            tqt = timeit(lambda: kernels._nf4_gemm(dy, st, None, True), iters=10)
+            line += f" | nf4 fwd {fl/tq/1e12:6.1f} TF/s dgrad {fl/tqt/1e12:6.1f} TF/s"
+        print(line)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("lora", "all"):
@@ -92,3 +118,5 @@ if __name__ == "__main__":
         attn()
     if which in ("norm", "all"):
         norm()
+    if which in ("gemm", "all"):
+        gemm()

@@ -534,20 +534,22 @@ def _lora_wgrad2(x2, u, dy2, t, A, B, s: float):
 
 
 class _LoRALinear(torch.autograd.Function):
-    """y = x Wᵀ + b + s·(x Aᵀ) Bᵀ with a frozen base (W, b).  The base products are library GEMMs;
-    everything rank-sized is the HIP kernels above, applied in place on the GEMM outputs."""
+    """y = x Wᵀ + b + s·(x Aᵀ) Bᵀ with a frozen base (W, b).  The base products are a GEMM (library for
+    bf16 weights, the NF4-fused kernel for 4-bit weights); everything rank-sized is the HIP kernels
+    above, applied in place on the GEMM outputs."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, B, s):
+    def forward(ctx, x, weight, bias, A, B, s, qstate):
         x2 = _rows(x)
         A, B = A.contiguous(), B.contiguous()
         with torch.cuda.device(x.device):
-            y2 = F.linear(x2, weight, bias)
+            y2 = F.linear(x2, weight, bias) if qstate is None else _nf4_gemm(x2, qstate, bias, False)
             t, Bt = _lora_fwd_(x2, y2, A, B, s)
         ctx.save_for_backward(x2, t, Bt, weight, A, B)
         ctx.s = s
+        ctx.qstate = qstate
         ctx.xshape = x.shape
-        return y2.view(*x.shape[:-1], weight.shape[0])
+        return y2.view(*x.shape[:-1], B.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -557,7 +559,7 @@ class _LoRALinear(torch.autograd.Function):
         dx = dA = dB = None
         with torch.cuda.device(dy.device):
             if ctx.needs_input_grad[0]:
-                dx2 = dy2 @ weight
+                dx2 = dy2 @ weight if ctx.qstate is None else _nf4_gemm(dy2, ctx.qstate, None, True)
                 u = _lora_bwd_dx_(dy2, dx2, Bt, A, s)
                 dx = dx2.view(ctx.xshape)
             else:  # input of a frozen trunk's first adapted layer: dx is unused, u = dy·B still needed
@@ -565,7 +567,7 @@ class _LoRALinear(torch.autograd.Function):
                 u = _lora_bwd_dx_(dy2, scratch, Bt, A, s)
             if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
                 dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B, s)
-        return dx, None, None, dA, dB, None
+        return dx, None, None, dA, dB, None, None
 
 
 class _LoRABranch(torch.autograd.Function):
@@ -609,8 +611,90 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
     if lora_down.shape[0] > 16:
         raise ValueError(f"LoRA rank {lora_down.shape[0]} > 16 is not supported by the MI355X kernels")
     if type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16:
-        return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale))
+        return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None)
+    if hasattr(base, "quant_state"):  # NF4Linear: dequant-fused GEMM for the base products
+        return _LoRALinear.apply(x, None, base.bias, lora_down, lora_up, float(scale), base.quant_state())
     y = base(x)
     if not y.is_contiguous():
         y = y.contiguous()
     return _LoRABranch.apply(x, y, lora_down, lora_up, float(scale))
+
+
+# =============================================================================================
+# GEMM on our MFMA kernel (bf16 weight) and NF4-fused linear
+# =============================================================================================
+def gemm_nt(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """x2 [M,K] @ weight[N,K]^T (+bias) with the hand-written MFMA kernel (vft_gemm_nt_bf16)."""
+    _ready(x2, weight)
+    _require_gpu(x2, weight, bias)
+    M, K = x2.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device), _Timed("gemm_nt_bf16", 2.0 * M * N * K):
+        st = _C.lib().vft_gemm_nt_bf16(_ptr(x2), _ptr(weight), _ptr(out), _ptr(bias), M, N, K, x2.stride(0),
+                                       weight.stride(0), out.stride(0), _stream())
+    _C.check(st, "vft_gemm_nt_bf16")
+    return out
+
+
+class NF4State:
+    """Device-side quantisation state of one NF4 weight (bitsandbytes layout, see modules/quant/nf4.py)."""
+
+    __slots__ = ("packed", "absmax", "absmax_is_u8", "nested_absmax", "nested_code", "code", "offset", "out_features",
+                 "in_features")
+
+    def __init__(self, packed, absmax, nested_absmax, nested_code, code, offset, out_features, in_features):
+        self.packed, self.absmax = packed, absmax
+        self.absmax_is_u8 = absmax.dtype == torch.uint8
+        self.nested_absmax, self.nested_code, self.code = nested_absmax, nested_code, code
+        self.offset, self.out_features, self.in_features = float(offset), int(out_features), int(in_features)
+
+
+def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool) -> torch.Tensor:
+    M = a2.shape[0]
+    N = q.in_features if transpose_w else q.out_features
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
+    K = q.out_features if transpose_w else q.in_features
+    with torch.cuda.device(a2.device), _Timed("gemm_nf4", 2.0 * M * N * K):
+        st = _C.lib().vft_gemm_nf4(_ptr(a2), _ptr(out), _ptr(bias), _ptr(q.packed), _ptr(q.absmax), int(q.absmax_is_u8),
+                                   _ptr(q.nested_absmax), _ptr(q.nested_code), _ptr(q.code), q.offset, q.out_features,
+                                   q.in_features, M, a2.stride(0), out.stride(0), int(transpose_w), _stream())
+    _C.check(st, "vft_gemm_nf4")
+    return out
+
+
+def nf4_dequantize(q: NF4State) -> torch.Tensor:
+    out = torch.empty((q.out_features, q.in_features), dtype=torch.bfloat16, device=q.packed.device)
+    with torch.cuda.device(out.device):
+        st = _C.lib().vft_nf4_dequant(_ptr(out), _ptr(q.packed), _ptr(q.absmax), int(q.absmax_is_u8), _ptr(q.nested_absmax),
+                                      _ptr(q.nested_code), _ptr(q.code), q.offset, q.out_features, q.in_features, _stream())
+    _C.check(st, "vft_nf4_dequant")
+    return out
+
+
+class _NF4Linear(torch.autograd.Function):
+    """y = x · dequant(W)ᵀ + b with the dequantisation fused into the GEMM prologue; backward gives
+    dx = dy · dequant(W) through the transposed-staging variant (the 4-bit weight is frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, q: NF4State, bias):
+        x2 = _rows(x)
+        y2 = _nf4_gemm(x2, q, bias, False)
+        ctx.q = q
+        ctx.xshape = x.shape
+        return y2.view(*x.shape[:-1], q.out_features)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _nf4_gemm(_rows(dy), ctx.q, None, True).view(ctx.xshape)
+        return dx, None, None
+
+
+def nf4_linear(x: torch.Tensor, q: NF4State, bias: torch.Tensor | None) -> torch.Tensor:
+    _ready(x)
+    _require_gpu(x, bias)
+    if x.shape[-1] != q.in_features:
+        raise ValueError(f"nf4_linear: input has {x.shape[-1]} features, weight expects {q.in_features}")
+    return _NF4Linear.apply(x, q, bias)
