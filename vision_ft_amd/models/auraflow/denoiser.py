@@ -27,6 +27,7 @@ from ...utils.tensor import module_dtype
 from .config import DenoiserConfig
 
 DENOISER_TENSOR_PREFIX = "model."
+_FREQ_CACHE: dict = {}
 
 _ACT = {"silu": nn.SiLU, "gelu": nn.GELU, "relu": nn.ReLU}
 
@@ -225,7 +226,11 @@ class TimestepEmbedder(nn.Module):
     @staticmethod
     def timestep_embedding(timestep: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
         half = dim // 2
-        freqs = 1000 * torch.exp(-math.log(max_period) * torch.arange(start=0, end=half) / half).to(timestep.device)
+        key = (dim, max_period, str(timestep.device))
+        freqs = _FREQ_CACHE.get(key)
+        if freqs is None:  # computed on the host exactly like the reference, then cached per device (graph-safe)
+            freqs = (1000 * torch.exp(-math.log(max_period) * torch.arange(start=0, end=half) / half)).to(timestep.device)
+            _FREQ_CACHE[key] = freqs
         args = timestep[:, None] * freqs[None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:
