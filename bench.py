@@ -16,6 +16,9 @@ import os
 import sys
 import time
 
+# NB: MIOpen's default (exhaustive) find is kept on purpose: it costs ~1-2 min in the first warm-up step on
+# a fresh box, but MIOPEN_FIND_MODE=FAST picks convolution kernels that make the whole SDXL step 1.34x slower.
+
 import torch
 import torch.distributed as dist
 

@@ -19,9 +19,9 @@
 //   * global->LDS staging goes through registers and is issued one tile ahead of the compute
 //     (issue loads early, write to LDS after the barrier).
 //
-// Backward is two kernels (no atomics, bitwise reproducible): dkdv (one workgroup per 128 keys,
-// loops over query tiles) and dq (one workgroup per 128 queries, loops over key tiles). Both
-// recompute P from the saved log-sum-exp.
+// Backward is two kernels (no atomics, bitwise reproducible): dq (one workgroup per 128 queries, loops
+// over key tiles; also produces delta = rowsum(dO*O)) and dkdv (one workgroup per 128 keys, loops over
+// query tiles). Both recompute P from the saved log-sum-exp.
 #include "vft_common.h"
 
 namespace {
@@ -310,7 +310,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
     const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq + qrow;
     const float lse2 = qok ? p.lse[srow] * kLog2e : INFINITY;
-    const float dl = qok ? p.delta[srow] : 0.f;
+    // delta = rowsum(dO * O), computed here (this kernel runs first) and published for the dK/dV kernel
+    float dl = 0.f;
+    {
+        const bf16_t* Ob = p.o + b * p.so.b + hq * p.so.h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 of = ldg_frag(Ob + (int64_t)qrow * p.so.s + ks * 16 + 8 * h, qok);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)dOf[ks][j];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (qok && h == 0) p.delta[srow] = dl;
+    }
     const float sc = p.scale * kLog2e;
 
     f32x16 dQ[DT];
@@ -565,9 +577,16 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <int D, int BQ>
 int launch_bwd(const AttnParams& p, hipStream_t st) {
     {
-        const int64_t nrows = (int64_t)p.B * p.Hq * p.Sq;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, p, D);
-        VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
+        constexpr size_t lds = 2 * 64 * (D + 8) * sizeof(bf16_t);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);  // also writes delta
+        VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
     {
         constexpr size_t lds = 2 * BQ * (D + 8) * sizeof(bf16_t) + 2 * BQ * sizeof(float);
@@ -580,18 +599,6 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
         dim3 grid((p.Sk + 127) / 128, p.Hkv, p.B);
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, BQ>), grid, dim3(256), lds, st, p);
         VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
-    }
-    {
-        constexpr size_t lds = 2 * 64 * (D + 8) * sizeof(bf16_t);
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
-        dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);
-        VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
     return 0;
 }
