@@ -1,0 +1,31 @@
+"""Tiny driver for rocprofv3 --pmc passes: runs the dominant hand-written kernels at their headline
+shapes a few times (SDXL self-attention fwd/bwd at B=16, LoRA rows fwd/bwd, wgrad).
+   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from vision_ft_amd import kernels  # noqa: E402
+
+dev = torch.device("cuda:0")
+bf = lambda *s: torch.randn(*s, device=dev, dtype=torch.float32).to(torch.bfloat16)  # noqa: E731
+
+B, H, S, D = 16, 10, 4096, 64
+q = bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True)
+k = bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True)
+v = bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True)
+do = bf(B, S, H, D).permute(0, 2, 1, 3)
+for _ in range(3):
+    kernels.flash_attention(q, k, v).backward(do)
+
+M, K, N, r = 65536, 640, 5120, 4
+x, y, dy, dx = bf(M, K), bf(M, N), bf(M, N), bf(M, K)
+A, Bw = bf(r, K), bf(N, r)
+for _ in range(3):
+    t, Bt = kernels._lora_fwd_(x, y, A, Bw, 0.25)
+    u = kernels._lora_bwd_dx_(dy, dx, Bt, A, 0.25)
+    kernels._lora_wgrad2(x, u, dy, t, A, Bw, 0.25)
+torch.cuda.synchronize()
+print("algorithmic bytes: attn_fwd q+k+v+o =", 4 * B * H * S * D * 2, " lora_fwd =", 2 * M * K + 4 * M * N,
+      " lora_bwd_dx =", 2 * M * N + 4 * M * K, " lora_wgrad2 =", 2 * M * (K + N))

@@ -59,10 +59,14 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // Transposed A-operand fragment for a 32(out rows = tile columns) x 16(k = tile rows) block of a
 // row-major [rows][ld] bf16 LDS tile.  The k order inside the step matches the packed-accumulator
 // B operand: element j of lane half h is tile row  row0 + 8*(j>>2) + 4*h + (j&3).
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0, int col0, int lane) {
-    const int h = lane >> 5;
-    const int i = lane & 15;
-    const bf16_t* a0 = tile + (row0 + 4 * h + (i >> 2)) * ld + col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+// `tr_lane_off` is the lane-dependent part of the address (loop invariant); row0/col0 are compile-time
+// constants at every call site and fold into the ds_read immediate offset.
+__device__ __forceinline__ int tr_lane_off(int ld, int lane) {
+    const int h = lane >> 5, i = lane & 15;
+    return (4 * h + (i >> 2)) * ld + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+}
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* lane_base, int ld, int row0, int col0) {
+    const bf16_t* a0 = lane_base + row0 * ld + col0;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * ld));
     s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -77,22 +81,51 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
     return r;
 }
 
-// register-staged copy of a ROWS x D bf16 tile into a padded LDS tile, 256 threads
+// register-staged copy of a ROWS x D bf16 tile into a padded LDS tile, 256 threads.  All per-thread
+// addressing is hoisted out of the tile loop: `init` computes this thread's global pointer / LDS slot /
+// row once; per tile only a uniform offset is added (the address math used to be ~40 % of the loop's
+// VALU instructions).
 template <int D, int ROWS>
 struct TileStage {
     static constexpr int CPR = D / 8;               // 16-byte chunks per row
     static constexpr int NCH = ROWS * CPR / 256;    // chunks per thread
+    static constexpr bool REG = (256 % CPR) == 0;   // chunk i of a thread = chunk 0 shifted by i*(256/CPR) rows
+    static constexpr int NP = REG ? 1 : NCH;
     static_assert(ROWS * CPR % 256 == 0, "tile must split evenly over 256 threads");
     u32x4 r[NCH];
+    const bf16_t* gp[NP];
+    int lrow[NP];
+    int loff[NP];
+    int64_t rstride;
 
-    __device__ __forceinline__ void load(const bf16_t* base, int64_t row_stride, int row0, int row_limit) {
+    __device__ __forceinline__ void init(const bf16_t* base, int64_t row_stride) {
+        constexpr int LD = D + 8;
+        rstride = row_stride;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int c = i * 256 + threadIdx.x;
             const int row = c / CPR, col = (c % CPR) * 8;
-            const int gr = row0 + row;
-            if (gr < row_limit) {
-                r[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)gr * row_stride + col);
+            gp[i] = base + (int64_t)row * row_stride + col;
+            lrow[i] = row;
+            loff[i] = row * LD + col;
+        }
+    }
+    // rows [row0, row0 + ROWS) of the tensor; rows >= row_limit are zero-filled
+    __device__ __forceinline__ void load(int row0, int row_limit) {
+        const int64_t toff = (int64_t)row0 * rstride;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const bf16_t* src;
+            int row;
+            if (REG) {
+                src = gp[0] + toff + (int64_t)(i * (256 / CPR)) * rstride;
+                row = lrow[0] + i * (256 / CPR);
+            } else {
+                src = gp[i % NP] + toff;
+                row = lrow[i % NP];
+            }
+            if (row0 + row < row_limit) {
+                r[i] = *reinterpret_cast<const u32x4*>(src);
             } else {
                 r[i] = u32x4{0u, 0u, 0u, 0u};
             }
@@ -102,9 +135,8 @@ struct TileStage {
         constexpr int LD = D + 8;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = i * 256 + threadIdx.x;
-            const int row = c / CPR, col = (c % CPR) * 8;
-            *reinterpret_cast<u32x4*>(lds + row * LD + col) = r[i];
+            const int off = REG ? loff[0] + i * (256 / CPR) * LD : loff[i % NP];
+            *reinterpret_cast<u32x4*>(lds + off) = r[i];
         }
     }
 };
@@ -126,18 +158,38 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
     *reinterpret_cast<bf16x4*>(p) = v;
 }
 
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (block id % 8), each with
+// its own L2.  All tiles of one (batch, head) stream the same K/V (or Q/dO) panels, so they are given
+// block ids that are congruent mod 8: heads are taken in groups of 8 (one per XCD) and a group's tiles
+// are interleaved.  Placement only affects speed; the mapping is a bijection onto (tile, head) pairs
+// plus idle tail blocks when the head count is not a multiple of 8.
+__device__ __forceinline__ bool xcd_map(int ntiles, int nheads, int& tile, int& head) {
+    const int L = blockIdx.x;
+    const int per_group = 8 * ntiles;
+    const int g = L / per_group, rem = L % per_group;
+    head = g * 8 + (rem & 7);
+    tile = rem >> 3;
+    return head < nheads;
+}
+__host__ inline unsigned xcd_grid(int ntiles, int nheads) { return (unsigned)(((nheads + 7) / 8) * 8 * ntiles); }
+
 // =============================================================================================
 // forward: one workgroup = 128 queries (4 waves x 32), key tiles of 64
 // =============================================================================================
+// (D <= 96: ask for 2 waves/SIMD => a 256-register budget, which makes hipcc emit the VGPR-destination
+// form of the MFMAs; with the default 512-register budget it parks S/P in AGPRs and pays ~130
+// v_accvgpr_read/write per key tile to get them to the VALU and back.)
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnParams p) {
     constexpr int LD = D + 8, KS = D / 16, DT = D / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + 64 * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * 128;
+    int qtile, bh;
+    if (!xcd_map((p.Sq + 127) / 128, p.B * p.Hq, qtile, bh)) return;  // block-uniform
+    const int b = bh / p.Hq, hq = bh % p.Hq, q0 = qtile * 128;
     const int hkv = hq / (p.Hq / p.Hkv);
     int kvl = p.Sk;
     if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
@@ -163,20 +215,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
     const int ntiles = (kvl + 63) / 64;
     TileStage<D, 64> kst, vst;
+    kst.init(Kb, p.sk.s);
+    vst.init(Vb, p.sv.s);
+    // K/V tiles are double-buffered in LDS: tile t+1 is written into the other buffer in the middle of
+    // tile t's compute (its global loads were issued one iteration earlier), so there is a single barrier
+    // per tile and neither HBM latency nor the LDS stores sit on the MFMA critical path.
+    constexpr int BUF = 2 * 64 * LD;
     if (ntiles > 0) {
-        kst.load(Kb, p.sk.s, 0, kvl);
-        vst.load(Vb, p.sv.s, 0, kvl);
-    }
-
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
+        kst.load(0, kvl);
+        vst.load(0, kvl);
         kst.store(Ks);
         vst.store(Vs);
-        __syncthreads();
-        if (t + 1 < ntiles) {
-            kst.load(Kb, p.sk.s, (t + 1) * 64, kvl);
-            vst.load(Vb, p.sv.s, (t + 1) * 64, kvl);
-        }
+    }
+    __syncthreads();
+    if (ntiles > 1) {
+        kst.load(64, kvl);
+        vst.load(64, kvl);
+    }
+    const int kfrag_off = r * LD + 8 * h;        // row-fragment offset of this lane
+    const int vtr_off = tr_lane_off(LD, lane);   // transposed-fragment offset of this lane
+
+    for (int t = 0; t < ntiles; ++t) {
+        const bf16_t* Kc = Ks + (t & 1) * BUF;
+        const bf16_t* kfrag = Kc + kfrag_off;
+        const bf16_t* vtr = Kc + 64 * LD + vtr_off;
 
         // S^T[key][q] = K Q^T
         f32x16 S[2];
@@ -186,12 +248,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             for (int i = 0; i < 16; ++i) S[kt][i] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * LD + ks * 16 + 8 * h);
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(kfrag + kt * 32 * LD + ks * 16);
                 S[kt] = mfma32(a, Qf[ks], S[kt]);
             }
         }
         const int n0 = t * 64;
-        if (n0 + 64 > kvl) {
+        if (n0 + 64 > kvl) {  // block-uniform: only the last key tile can be ragged
+            // the empty asm keeps this a real branch (otherwise it is if-converted into ~100 selects per tile)
+            asm volatile("; ragged tail tile" ::: "memory");
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -219,23 +283,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             }
         lsum = lsum * alpha + psum;
         m = m_new;
+        // exact skip: once the running maxima have settled no lane needs a rescale (alpha == 1 everywhere)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+        }
 
         bf16x8 Pf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) Pf[kk] = pack8(S[kk >> 1], kk & 1);
+
+        if (t + 1 < ntiles) {  // stage tile t+1 into the other buffer; then start fetching tile t+2
+            bf16_t* Kn = Ks + ((t + 1) & 1) * BUF;
+            kst.store(Kn);
+            vst.store(Kn + 64 * LD);
+            if (t + 2 < ntiles) {
+                kst.load((t + 2) * 64, kvl);
+                vst.load((t + 2) * 64, kvl);
+            }
+        }
 
         // O^T[d][q] += V^T P^T
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 a = tr_frag(Vs, LD, kk * 16, dt * 32, lane);
+                bf16x8 a = tr_frag(vtr, LD, kk * 16, dt * 32);
                 O[dt] = mfma32(a, Pf[kk], O[dt]);
             }
+        __syncthreads();
     }
 
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -282,14 +360,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p, int D) {
 // backward dQ: one workgroup = 128 queries, key tiles of 64
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnParams p) {
     constexpr int LD = D + 8, KS = D / 16, DT = D / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + 64 * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hq = blockIdx.y, q0 = blockIdx.x * 128;
+    int qtile, bh;
+    if (!xcd_map((p.Sq + 127) / 128, p.B * p.Hq, qtile, bh)) return;  // block-uniform
+    const int b = bh / p.Hq, hq = bh % p.Hq, q0 = qtile * 128;
     const int hkv = hq / (p.Hq / p.Hkv);
     int kvl = p.Sk;
     if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
@@ -333,19 +413,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 
     const int ntiles = (kvl + 63) / 64;
     TileStage<D, 64> kst, vst;
+    kst.init(Kb, p.sk.s);
+    vst.init(Vb, p.sv.s);
+    constexpr int BUF = 2 * 64 * LD;  // double-buffered K/V tiles, one barrier per tile (see the forward kernel)
     if (ntiles > 0) {
-        kst.load(Kb, p.sk.s, 0, kvl);
-        vst.load(Vb, p.sv.s, 0, kvl);
-    }
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
+        kst.load(0, kvl);
+        vst.load(0, kvl);
         kst.store(Ks);
         vst.store(Vs);
-        __syncthreads();
-        if (t + 1 < ntiles) {
-            kst.load(Kb, p.sk.s, (t + 1) * 64, kvl);
-            vst.load(Vb, p.sv.s, (t + 1) * 64, kvl);
-        }
+    }
+    __syncthreads();
+    if (ntiles > 1) {
+        kst.load(64, kvl);
+        vst.load(64, kvl);
+    }
+    const int frag_off = r * LD + 8 * h;
+    const int tr_off = tr_lane_off(LD, lane);
+    for (int t = 0; t < ntiles; ++t) {
+        const bf16_t* Kc = Ks + (t & 1) * BUF;
+        const bf16_t* kfrag = Kc + frag_off;
+        const bf16_t* vfrag = Kc + 64 * LD + frag_off;
+        const bf16_t* ktr = Kc + tr_off;
         const int n0 = t * 64;
         bf16x8 dSf[4];
 #pragma unroll
@@ -358,29 +446,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * LD + ks * 16 + 8 * h);
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(kfrag + kt * 32 * LD + ks * 16);
                 S = mfma32(a, Qf[ks], S);
-                bf16x8 c = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + r) * LD + ks * 16 + 8 * h);
+                bf16x8 c = *reinterpret_cast<const bf16x8*>(vfrag + kt * 32 * LD + ks * 16);
                 dP = mfma32(c, dOf[ks], dP);
+            }
+            if (n0 + 64 > kvl) {  // ragged last tile: masked keys contribute nothing
+                asm volatile("; ragged tail tile" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = n0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= kvl) S[i] = -INFINITY;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = n0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                float pv = __builtin_amdgcn_exp2f(S[i] * sc - lse2);
-                if (key >= kvl) pv = 0.f;
+                const float pv = __builtin_amdgcn_exp2f(S[i] * sc - lse2);
                 S[i] = pv * (dP[i] - dl);
             }
             dSf[kt * 2] = pack8(S, 0);
             dSf[kt * 2 + 1] = pack8(S, 1);
+        }
+        if (t + 1 < ntiles) {
+            bf16_t* Kn = Ks + ((t + 1) & 1) * BUF;
+            kst.store(Kn);
+            vst.store(Kn + 64 * LD);
+            if (t + 2 < ntiles) {
+                kst.load((t + 2) * 64, kvl);
+                vst.load((t + 2) * 64, kvl);
+            }
         }
         // dQ^T[d][q] += K^T dS^T
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 a = tr_frag(Ks, LD, kk * 16, dt * 32, lane);
+                bf16x8 a = tr_frag(ktr, LD, kk * 16, dt * 32);
                 dQ[dt] = mfma32(a, dSf[kk], dQ[dt]);
             }
+        __syncthreads();
     }
     if (qok) {
         const float s = p.scale;
@@ -399,7 +503,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // loops over the query heads that share this kv head
 // =============================================================================================
 template <int D, int BQ>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnParams p) {
     constexpr int LD = D + 8, KS = D / 16, DT = D / 32, QT = BQ / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
@@ -408,7 +512,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     float* dl_s = lse_s + BQ;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hkv = blockIdx.y, n0 = blockIdx.x * 128;
+    int ktile, bh;
+    if (!xcd_map((p.Sk + 127) / 128, p.B * p.Hkv, ktile, bh)) return;  // block-uniform
+    const int b = bh / p.Hkv, hkv = bh % p.Hkv, n0 = ktile * 128;
     const int G = p.Hq / p.Hkv;
     int kvl = p.Sk;
     if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
@@ -442,13 +548,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     const int niter = (n0 < kvl) ? G * nqt : 0;   // fully masked key blocks get zero gradients
     TileStage<D, BQ> qst, dost;
     float lse_r = INFINITY, dl_r = 0.f;
+    int cur_g = -1;
+    const bf16_t* qfrag = Qs + r * LD + 8 * h;
+    const bf16_t* dofrag = dOs + r * LD + 8 * h;
+    const bf16_t* qtr = Qs + tr_lane_off(LD, lane);
+    const bf16_t* dotr = dOs + tr_lane_off(LD, lane);
     auto prefetch = [&](int it) {
         const int g = it / nqt, t = it % nqt;
         const int hq = hkv * G + g;
-        const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
-        const bf16_t* dOb = p.dout + b * p.sdo.b + hq * p.sdo.h;
-        qst.load(Qb, p.sq.s, t * BQ, p.Sq);
-        dost.load(dOb, p.sdo.s, t * BQ, p.Sq);
+        if (g != cur_g) {  // block-uniform: next query head of the GQA group
+            qst.init(p.q + b * p.sq.b + hq * p.sq.h, p.sq.s);
+            dost.init(p.dout + b * p.sdo.b + hq * p.sdo.h, p.sdo.s);
+            cur_g = g;
+        }
+        qst.load(t * BQ, p.Sq);
+        dost.load(t * BQ, p.Sq);
         if (tid < BQ) {
             const int q = t * BQ + tid;
             const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq + q;
@@ -480,9 +594,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + r) * LD + ks * 16 + 8 * h);
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(qfrag + qt * 32 * LD + ks * 16);
                 S = mfma32(a, Kf[ks], S);
-                bf16x8 c = *reinterpret_cast<const bf16x8*>(dOs + (qt * 32 + r) * LD + ks * 16 + 8 * h);
+                bf16x8 c = *reinterpret_cast<const bf16x8*>(dofrag + qt * 32 * LD + ks * 16);
                 dP = mfma32(c, Vf[ks], dP);
             }
 #pragma unroll
@@ -507,9 +621,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int kk = 0; kk < 2 * QT; ++kk) {
-                bf16x8 a = tr_frag(dOs, LD, kk * 16, dt * 32, lane);
+                bf16x8 a = tr_frag(dotr, LD, kk * 16, dt * 32);
                 dV[dt] = mfma32(a, Pf[kk], dV[dt]);
-                bf16x8 c = tr_frag(Qs, LD, kk * 16, dt * 32, lane);
+                bf16x8 c = tr_frag(qtr, LD, kk * 16, dt * 32);
                 dK[dt] = mfma32(c, dSf[kk], dK[dt]);
             }
     }
@@ -555,20 +669,20 @@ int check_dims(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     VFT_CHECK_ARG(B > 0 && Hq > 0 && Hkv > 0 && Sq > 0 && Sk > 0, "vft_attn: non-positive dimension");
     VFT_CHECK_ARG(Hq % Hkv == 0, "vft_attn: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     VFT_CHECK_ARG(D == 64 || D == 96 || D == 128 || D == 256, "vft_attn: head_dim %d unsupported (64, 96, 128, 256)", D);
-    VFT_CHECK_ARG(B <= 65535 && Hq <= 65535, "vft_attn: batch/heads exceed grid limits");
+    VFT_CHECK_ARG((int64_t)B * Hq * ((Sq + 127) / 128 + (Sk + 127) / 128) < (1ll << 30), "vft_attn: problem exceeds grid limits");
     return 0;
 }
 
 template <int D>
 int launch_fwd(const AttnParams& p, hipStream_t st) {
-    constexpr size_t lds = 2 * 64 * (D + 8) * sizeof(bf16_t);
+    constexpr size_t lds = 2 * 2 * 64 * (D + 8) * sizeof(bf16_t);  // double-buffered K + V tiles
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr = true;
     }
-    dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+    dim3 grid(xcd_grid((p.Sq + 127) / 128, p.B * p.Hq));
     hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, dim3(256), lds, st, p);
     VFT_CHECK_LAUNCH("vft_attn_fwd");
     return 0;
@@ -577,14 +691,14 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <int D, int BQ>
 int launch_bwd(const AttnParams& p, hipStream_t st) {
     {
-        constexpr size_t lds = 2 * 64 * (D + 8) * sizeof(bf16_t);
+        constexpr size_t lds = 2 * 2 * 64 * (D + 8) * sizeof(bf16_t);
         static bool attr = false;
         if (!attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+        dim3 grid(xcd_grid((p.Sq + 127) / 128, p.B * p.Hq));
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);  // also writes delta
         VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
@@ -596,7 +710,7 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        dim3 grid((p.Sk + 127) / 128, p.Hkv, p.B);
+        dim3 grid(xcd_grid((p.Sk + 127) / 128, p.B * p.Hkv));
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, BQ>), grid, dim3(256), lds, st, p);
         VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
     }
