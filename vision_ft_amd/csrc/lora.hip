@@ -85,18 +85,39 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
     }
     __syncthreads();
     // ---- phase 2 ----
+    // Thread map: the N/8 column groups are cut into passes of cw <= 128 groups and the 256 threads
+    // cover cw groups x rp rows at once, so narrow layers (N = 640: 80 groups) still use ~all lanes.
     const int nrows = min(16, M - m0);
-    for (int n0 = tid * 8; n0 < N; n0 += 2048) {
+    const int G = N >> 3;
+    const int npass = (G + 127) >> 7;
+    const int cw = (G + npass - 1) / npass;
+    const int rp = 256 / cw;
+    const int lr = tid / cw, lc = tid - lr * cw;
+    if (lr >= rp) return;
+    for (int c0 = 0; c0 < G; c0 += cw) {
+        if (c0 + lc >= G) break;
+        const int n0 = (c0 + lc) * 8;
         for (int j0 = 0; j0 < r; j0 += RC) {
             float wreg[8][RC];
             if (NJ) {
                 // w2[n*r + j]: the 8 columns' coefficients are one contiguous run of 8*r elements
+                if (r == RC) {
+                    bf16x8 wv[RC];
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
+                    for (int q = 0; q < RC; ++q)
+                        wv[q] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)n0 * RC + 8 * q);
 #pragma unroll
-                    for (int j = 0; j < RC; ++j)
-                        wreg[c][j] = (j0 + j < r) ? s * (float)w2[(int64_t)(n0 + c) * r + j0 + j] : 0.f;
-                if (w2t_out != nullptr && blockIdx.x == 0) {
+                    for (int c = 0; c < 8; ++c)
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) wreg[c][j] = s * (float)wv[(c * RC + j) >> 3][(c * RC + j) & 7];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+#pragma unroll
+                        for (int j = 0; j < RC; ++j)
+                            wreg[c][j] = (j0 + j < r) ? s * (float)w2[(int64_t)(n0 + c) * r + j0 + j] : 0.f;
+                }
+                if (w2t_out != nullptr && blockIdx.x == 0 && lr == 0) {
 #pragma unroll
                     for (int j = 0; j < RC; ++j)
                         if (j0 + j < r) {
@@ -115,20 +136,30 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
                     for (int c = 0; c < 8; ++c) wreg[c][j] = s * (float)v[c];
                 }
             }
-            for (int i = 0; i < nrows; ++i) {
-                bf16_t* yp = y + (int64_t)(m0 + i) * ldy + n0;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(yp);
-                float tv[RC];
+            // rows in batches of 4: all loads of a batch are in flight before the first FMA
+            for (int i0 = lr; i0 < nrows; i0 += 4 * rp) {
+                bf16x8 v[4];
 #pragma unroll
-                for (int j = 0; j < RC; ++j) tv[j] = (j0 + j < 16) ? ps[i][(j0 + j) & 15] : 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float a = (float)v[c];
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) a = fmaf(tv[j], wreg[c][j], a);
-                    v[c] = (bf16_t)a;
+                for (int b = 0; b < 4; ++b) {
+                    const int i = i0 + b * rp;
+                    if (i < nrows) v[b] = *reinterpret_cast<const bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0);
                 }
-                *reinterpret_cast<bf16x8*>(yp) = v;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = i0 + b * rp;
+                    if (i >= nrows) break;
+                    float tv[RC];
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) tv[j] = (j0 + j < 16) ? ps[i][(j0 + j) & 15] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float a = (float)v[b][c];
+#pragma unroll
+                        for (int j = 0; j < RC; ++j) a = fmaf(tv[j], wreg[c][j], a);
+                        v[b][c] = (bf16_t)a;
+                    }
+                    *reinterpret_cast<bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0) = v[b];
+                }
             }
         }
     }
