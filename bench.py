@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-gemm-table", action="store_true", help="library GEMMs use their default heuristic, not the committed table")
+    ap.add_argument("--tune-gemms", action="store_true", help="time library GEMM solutions for missing shapes and update the table")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,8 +151,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    from vision_ft_amd import kernels
+    from vision_ft_amd import kernels, tuning
     from vision_ft_amd.trainer.dp import DataParallelGrads
+
+    gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
 
     batch = args.batch or {"sdxl_lora": 16, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4}[args.workload]
     model = build(args.workload, device)
@@ -224,7 +228,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "resolution": "1024x1024", "per_gpu_batch": batch,
-                       "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph,
+                       "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph, "gemm_table": bool(gemm_table),
                        "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5)},
             "roofline": roofline,
         }

@@ -51,6 +51,8 @@ class TrainerConfig(BaseModel):
     allow_tf32: bool = False
     # MI355X extension: capture each bucket shape's step into HIP graphs (vision_ft_amd/trainer/graph.py)
     hip_graph: bool = True
+    # MI355X extension: pick library GEMM solutions from the committed gfx950 table (vision_ft_amd/tuning.py)
+    tuned_gemms: bool = True
 
 
 class TrainConfig(BaseModel):

@@ -134,6 +134,10 @@ class Trainer:
     def before_train(self) -> None:
         if self.config.trainer.fp32_matmul_precision is not None:
             torch.set_float32_matmul_precision(self.config.trainer.fp32_matmul_precision)
+        if self.config.trainer.tuned_gemms and torch.cuda.is_available():
+            from .. import tuning
+
+            tuning.enable()
         set_seed(self.seed)
         self.prepare_dataloaders()
         self.prepare_saving_strategy()
