@@ -129,6 +129,15 @@ int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bi
 int vft_groupnorm_bwd(const void* x, const void* dy, const float* stats, const void* weight,
                       const void* bias, void* dx, float* bstats, float* dweight, float* dbias, int N,
                       int C, int HW, int G, float eps, int fuse_silu, void* stream);
+/* Channels-last variants: x / y / dy / dx are [N][HW][C] (C % 8 == 0, C <= 2560), everything else as
+ * above, same statistics layout.  The SDXL UNet runs NHWC end to end on MI355X: the convolutions are
+ * NHWC-native and (N, HW, C) is the SpatialTransformer's token layout (sdxl/denoiser.py:303-330), so the
+ * reference's permute + reshape copies around every transformer disappear. */
+int vft_groupnorm_nhwc_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats,
+                           int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
+int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float* stats, const void* weight,
+                           const void* bias, void* dx, float* bstats, float* dweight, float* dbias,
+                           int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
 
 /* ---- gated activations / gated residual ------------------------------------------------------
  * GEGLU: out[M,F] = proj[:, :F] * gelu(proj[:, F:])   (sdxl/denoiser.py:183-186, exact erf GELU)
@@ -142,6 +151,18 @@ int vft_swiglu_fwd(const void* a, const void* b, void* out, int64_t n, void* str
 int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void* db, int64_t n, void* stream);
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,
                       int C, int rows_per_batch, int use_tanh, void* stream);
+
+/* ---- fused linear layer (bf16 weight) ----------------------------------------------------------
+ * y[M,N] = x[M,K] . w[N,K]^T (+ bias[N]) (+ ext_x[M,r] . ext_w[N,r]^T) (+ residual[M,N])
+ * One launch for the reference's LoRALinear.forward (peft/lora.py:92-104: linear(x) + lora_up(lora_down(x)) * s):
+ * ext_x = lora_down(x) (vft_lora_down), ext_w = s * lora_up; and for the `x + attn(x)` / `x + ff(x)` residual
+ * adds of the transformer blocks (sdxl/denoiser.py:273-284).  The data gradient dx = dy.W + (dy.B).(sA) is the
+ * same call on the transposed weight.  K % 64 == 0, N % 8 == 0, strides % 8 == 0, 16-byte aligned pointers;
+ * r in {4, 8, 16, 32} when the rank extension is present (ext_x / ext_w dense [.,r]).
+ */
+int vft_linear_fwd(const void* x, const void* w, void* y, const void* bias, const void* residual,
+                   const void* ext_x, const void* ext_w, int M, int N, int K, int r, int64_t ldx,
+                   int64_t ldw, int64_t ldy, int64_t ldres, void* stream);
 
 /* ---- GEMM (bf16 / NF4 weight) ----------------------------------------------------------------
  * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, weight B row-major [out,in]

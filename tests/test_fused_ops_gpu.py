@@ -77,6 +77,29 @@ def test_group_norm_silu(gpu, N, C, H, W, silu, eps):
     _run(lambda x, w, b: kernels.group_norm(x, w, b, 32, eps, silu=silu), ref, [x, w, b], gpu, (0, 1, 2))
 
 
+@pytest.mark.parametrize("N,C,H,W,silu,eps", [(2, 320, 32, 32, True, 1e-5), (3, 640, 16, 24, False, 1e-6),
+                                               (1, 1280, 8, 8, True, 1e-5), (2, 960, 7, 9, True, 1e-5),
+                                               (1, 2560, 5, 5, True, 1e-5), (2, 1920, 4, 6, False, 1e-5),
+                                               (2, 64, 4, 4, True, 1e-5), (16, 320, 64, 64, True, 1e-5)])
+def test_group_norm_silu_channels_last(gpu, N, C, H, W, silu, eps):
+    """Same op on channels-last storage (the layout the SDXL UNet runs in); output keeps the format."""
+    from vision_ft_amd import kernels
+
+    g = _g(5)
+    x, w, b = _bf(g, N, C, H, W, sc=2.0, off=0.3), _bf(g, C, sc=0.2, off=1.0), _bf(g, C, sc=0.1)
+
+    def ref(x, w, b):
+        y = F.group_norm(x, 32, w, b, eps)
+        return F.silu(y) if silu else y
+
+    def hip(x, w, b):
+        y = kernels.group_norm(x.contiguous(memory_format=torch.channels_last), w, b, 32, eps, silu=silu)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        return y
+
+    _run(hip, ref, [x, w, b], gpu, (0, 1, 2))
+
+
 def test_geglu_swiglu_gate_residual(gpu):
     from vision_ft_amd import kernels
 

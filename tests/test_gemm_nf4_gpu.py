@@ -170,3 +170,43 @@ def test_qlora_tiny_lumina_step(gpu):
     assert len(grads) == 2 * 15 and all(gr is not None and torch.isfinite(gr.float()).all() for gr in grads)
     assert any(gr.abs().sum() > 0 for gr in grads)
     assert all(p.grad is None for n, p in qmodel.named_parameters() if "lora_" not in n)
+
+
+@pytest.mark.parametrize("M,N,K,r,bias,res", [(4096, 1280, 1280, 4, True, True), (1000, 640, 2048, 8, False, False),
+                                              (333, 5120, 640, 16, True, False), (300, 648, 64, 32, True, True),
+                                              (777, 1024, 96, 0, True, True), (1, 8, 32, 4, False, False),
+                                              (8720, 3072, 3072, 16, True, False), (513, 2304, 320, 0, False, False)])
+def test_linear_fused(gpu, M, N, K, r, bias, res):
+    """vft_linear_fwd: base GEMM + bias + rank-r extension in the accumulator + residual on the rounded
+    output, vs fp32 math (both tile configurations, ragged M / N edges, every supported rank)."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(7)
+    x, w = _bf(g, M, K), _bf(g, N, K, sc=K**-0.5)
+    b = _bf(g, N, sc=0.2) if bias else None
+    rs = _bf(g, M, N) if res else None
+    ex = _bf(g, M, r, sc=0.5) if r else None
+    ew = _bf(g, N, r, sc=0.5) if r else None
+    y = kernels.linear_fused(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), None if rs is None else rs.to(gpu),
+                             None if ex is None else ex.to(gpu), None if ew is None else ew.to(gpu))
+    ref = x.float() @ w.float().t()
+    if b is not None:
+        ref = ref + b.float()
+    if r:
+        ref = ref + ex.float() @ ew.float().t()
+    if rs is not None:
+        ref = ref.to(torch.bfloat16).float() + rs.float()
+    assert y.shape == (M, N)
+    assert rel_err(y.cpu(), ref) < 5e-3, rel_err(y.cpu(), ref)
+
+
+def test_linear_fused_rejects_bad_arguments(gpu):
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(8)
+    x, w = _bf(g, 64, 48).to(gpu), _bf(g, 64, 48).to(gpu)  # K % 32 != 0
+    with pytest.raises(ValueError):
+        kernels.linear_fused(x, w)
+    x, w = _bf(g, 64, 64).to(gpu), _bf(g, 64, 64).to(gpu)
+    with pytest.raises(ValueError):
+        kernels.linear_fused(x, w, ext_x=_bf(g, 64, 5).to(gpu), ext_w=_bf(g, 64, 5).to(gpu))  # unsupported rank

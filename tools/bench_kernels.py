@@ -110,6 +110,25 @@ def gemm():
         print(line)
 
 
+def linear():
+    import torch.nn.functional as F
+
+    print("== fused linear (vft_linear_fwd) vs hipBLASLt F.linear; +lora = rank-4 extension fused vs F.linear + lora_fwd pass ==")
+    for M, N, K in [(65536, 640, 640), (65536, 5120, 640), (65536, 640, 2560), (16384, 1280, 1280), (16384, 10240, 1280),
+                    (16384, 1280, 5120), (65536, 640, 5760), (16384, 1280, 11520), (262144, 320, 2880), (8720, 3072, 3072)]:
+        x, w, b = bf(M, K), bf(N, K) * 0.05, bf(N)
+        ex, ew = bf(M, 4), bf(N, 4)
+        y = kernels.linear_fused(x, w, b)
+        ref = F.linear(x, w, b)
+        err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+        to = timeit(lambda: kernels.linear_fused(x, w, b), iters=10)
+        te = timeit(lambda: kernels.linear_fused(x, w, b, ext_x=ex, ext_w=ew), iters=10)
+        tl = timeit(lambda: F.linear(x, w, b), iters=10)
+        fl = 2.0 * M * N * K
+        print(f"M={M:6d} N={N:5d} K={K:5d} | ours {to*1e6:8.1f} us {fl/to/1e12:7.1f} TF/s | +ext {te*1e6:8.1f} us | hipBLASLt {tl*1e6:8.1f} us "
+              f"{fl/tl/1e12:7.1f} TF/s | rel err {err:.2e}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("lora", "all"):
@@ -120,3 +139,5 @@ if __name__ == "__main__":
         norm()
     if which in ("gemm", "all"):
         gemm()
+    if which in ("linear", "all"):
+        linear()

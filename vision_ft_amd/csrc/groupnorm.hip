@@ -1,4 +1,4 @@
-// GroupNorm (+ fused SiLU) over NCHW bf16 activations, fp32 statistics — gfx950.
+// GroupNorm (+ fused SiLU) over NCHW or NHWC bf16 activations, fp32 statistics — gfx950.
 //
 // Replaces cuDNN/ATen GroupNorm followed by a separate SiLU in the SDXL ResidualBlock
 // (src/models/sdxl/denoiser.py:511-551, GN32 eps 1e-5 -> SiLU -> conv) and the SpatialTransformer
@@ -171,6 +171,281 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const bf16_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channels-last variant: x[N][HW][C].  The whole UNet runs NHWC on MI355X (MIOpen's implicit-GEMM
+// convolutions are NHWC-native, and (N, HW, C) *is* the token layout of the SpatialTransformer, so
+// no permute copies are left).  A group is no longer contiguous, so threads own a fixed 8-channel
+// vector (cv) and walk rows: block = CV x R threads (CV = C/8), thread (cv, lr) visits rows
+// lr, lr+R, ... of the block's row chunk.  Per-channel constants live in registers for the whole
+// walk; the per-group sums are folded through LDS and then 2·G global atomics per block.
+// Same statistics layout as the NCHW path: stats[(n*G+g)*2 + {0,1}] = (Σx, Σx²).
+// ---------------------------------------------------------------------------------------------
+struct NhwcGeom {
+    int C, HW, cpg, G, CV, R, rows_per_block;
+};
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// fold 8 per-channel pairs into the LDS per-group accumulators (runs of equal group first)
+__device__ __forceinline__ void fold_groups(float* gacc, int c0, int cpg, const float (&a)[8], const float (&b)[8]) {
+    int g = c0 / cpg;
+    int left = cpg - (c0 - g * cpg);  // channels of group g remaining from c0 on
+    float ra = 0.f, rb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (left == 0) {
+            atomicAdd(&gacc[g * 2], ra);
+            atomicAdd(&gacc[g * 2 + 1], rb);
+            ra = rb = 0.f;
+            ++g;
+            left = cpg;
+        }
+        ra += a[i];
+        rb += b[i];
+        --left;
+    }
+    atomicAdd(&gacc[g * 2], ra);
+    atomicAdd(&gacc[g * 2 + 1], rb);
+}
+
+__global__ __launch_bounds__(320) void gn_nhwc_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats,
+                                                            NhwcGeom gm) {
+    extern __shared__ float gacc[];  // [G*2]
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < gm.G * 2; i += blockDim.x) gacc[i] = 0.f;
+    __syncthreads();
+    const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
+    const int r0 = blockIdx.x * gm.rows_per_block;
+    const int r1 = min(r0 + gm.rows_per_block, gm.HW);
+    const bf16_t* xp = x + ((int64_t)n * gm.HW) * gm.C + cv * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    int r = r0 + lr;
+    for (; r + 3 * gm.R < r1; r += 4 * gm.R) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ld8(xp + (int64_t)(r + u * gm.R) * gm.C, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s1[i] += v[u][i];
+                s2[i] += v[u][i] * v[u][i];
+            }
+    }
+    for (; r < r1; r += gm.R) {
+        float v[8];
+        ld8(xp + (int64_t)r * gm.C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s1[i] += v[i];
+            s2[i] += v[i] * v[i];
+        }
+    }
+    fold_groups(gacc, cv * 8, gm.cpg, s1, s2);
+    __syncthreads();
+    for (int i = tid; i < gm.G * 2; i += blockDim.x) atomicAdd(stats + (int64_t)n * gm.G * 2 + i, gacc[i]);
+}
+
+// per-channel constants of thread's 8 channels
+struct ChanConst {
+    float mean[8], rstd[8], w[8], b[8];
+};
+__device__ __forceinline__ void load_chan_const(ChanConst& k, const float* stats, const bf16_t* w, const bf16_t* b, int n,
+                                                int c0, const NhwcGeom& gm, float eps) {
+    const float invL = 1.f / ((float)gm.cpg * (float)gm.HW);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i;
+        const float* st = stats + ((int64_t)n * gm.G + c / gm.cpg) * 2;
+        k.mean[i] = st[0] * invL;
+        k.rstd[i] = rsqrtf(fmaxf(st[1] * invL - k.mean[i] * k.mean[i], 0.f) + eps);
+        k.w[i] = w ? (float)w[c] : 1.f;
+        k.b[i] = b ? (float)b[c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(320) void gn_nhwc_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                            const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                            bf16_t* __restrict__ y, NhwcGeom gm, float eps, int silu) {
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
+    ChanConst k;
+    load_chan_const(k, stats, w, b, n, cv * 8, gm, eps);
+    float a[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = k.rstd[i] * k.w[i];
+        o[i] = k.b[i] - k.mean[i] * a[i];
+    }
+    const int r0 = blockIdx.x * gm.rows_per_block;
+    const int r1 = min(r0 + gm.rows_per_block, gm.HW);
+    const int64_t base = ((int64_t)n * gm.HW) * gm.C + cv * 8;
+    int r = r0 + lr;
+    for (; r + 3 * gm.R < r1; r += 4 * gm.R) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ld8(x + base + (int64_t)(r + u * gm.R) * gm.C, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float z = v[u][i] * a[i] + o[i];
+                v[u][i] = silu ? silu_f(z) : z;
+            }
+            st8(y + base + (int64_t)(r + u * gm.R) * gm.C, v[u]);
+        }
+    }
+    for (; r < r1; r += gm.R) {
+        float v[8];
+        ld8(x + base + (int64_t)r * gm.C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float z = v[i] * a[i] + o[i];
+            v[i] = silu ? silu_f(z) : z;
+        }
+        st8(y + base + (int64_t)r * gm.C, v);
+    }
+}
+
+__global__ __launch_bounds__(320) void gn_nhwc_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                const float* __restrict__ stats,
+                                                                const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                                float* __restrict__ bstats, float* __restrict__ dw,
+                                                                float* __restrict__ db, NhwcGeom gm, float eps, int silu) {
+    extern __shared__ float gacc[];  // [G*2]
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < gm.G * 2; i += blockDim.x) gacc[i] = 0.f;
+    __syncthreads();
+    const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
+    ChanConst k;
+    load_chan_const(k, stats, w, b, n, cv * 8, gm, eps);
+    const int r0 = blockIdx.x * gm.rows_per_block;
+    const int r1 = min(r0 + gm.rows_per_block, gm.HW);
+    const int64_t base = ((int64_t)n * gm.HW) * gm.C + cv * 8;
+    float sz[8], szx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sz[i] = szx[i] = 0.f;
+    for (int r = r0 + lr; r < r1; r += 2 * gm.R) {
+        float v[2][8], d[2][8];
+        const bool two = r + gm.R < r1;
+        ld8(x + base + (int64_t)r * gm.C, v[0]);
+        ld8(dy + base + (int64_t)r * gm.C, d[0]);
+        if (two) {
+            ld8(x + base + (int64_t)(r + gm.R) * gm.C, v[1]);
+            ld8(dy + base + (int64_t)(r + gm.R) * gm.C, d[1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[u][i] - k.mean[i]) * k.rstd[i];
+                float dz = d[u][i];
+                if (silu) dz *= dsilu_f(xh * k.w[i] + k.b[i]);
+                sz[i] += dz;
+                szx[i] += dz * xh;
+            }
+        }
+    }
+    if (dw != nullptr || db != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (dw) atomicAdd(dw + cv * 8 + i, szx[i]);
+            if (db) atomicAdd(db + cv * 8 + i, sz[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sz[i] *= k.w[i];
+        szx[i] *= k.w[i];
+    }
+    fold_groups(gacc, cv * 8, gm.cpg, sz, szx);
+    __syncthreads();
+    for (int i = tid; i < gm.G * 2; i += blockDim.x) atomicAdd(bstats + (int64_t)n * gm.G * 2 + i, gacc[i]);
+}
+
+__global__ __launch_bounds__(320) void gn_nhwc_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ bstats, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ b, bf16_t* __restrict__ dx,
+                                                             NhwcGeom gm, float eps, int silu) {
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
+    ChanConst k;
+    load_chan_const(k, stats, w, b, n, cv * 8, gm, eps);
+    float mg[8], mgx[8];
+    {
+        const float invL = 1.f / ((float)gm.cpg * (float)gm.HW);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* bs = bstats + ((int64_t)n * gm.G + (cv * 8 + i) / gm.cpg) * 2;
+            mg[i] = bs[0] * invL;
+            mgx[i] = bs[1] * invL;
+        }
+    }
+    const int r0 = blockIdx.x * gm.rows_per_block;
+    const int r1 = min(r0 + gm.rows_per_block, gm.HW);
+    const int64_t base = ((int64_t)n * gm.HW) * gm.C + cv * 8;
+    for (int r = r0 + lr; r < r1; r += 2 * gm.R) {
+        float v[2][8], d[2][8];
+        const bool two = r + gm.R < r1;
+        ld8(x + base + (int64_t)r * gm.C, v[0]);
+        ld8(dy + base + (int64_t)r * gm.C, d[0]);
+        if (two) {
+            ld8(x + base + (int64_t)(r + gm.R) * gm.C, v[1]);
+            ld8(dy + base + (int64_t)(r + gm.R) * gm.C, d[1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[u][i] - k.mean[i]) * k.rstd[i];
+                float dz = d[u][i];
+                if (silu) dz *= dsilu_f(xh * k.w[i] + k.b[i]);
+                v[u][i] = k.rstd[i] * (dz * k.w[i] - mg[i] - xh * mgx[i]);
+            }
+            st8(dx + base + (int64_t)(r + u * gm.R) * gm.C, v[u]);
+        }
+    }
+}
+
+// block = CV x R threads (<= 320); rows per block sized for >= ~2048 blocks in flight
+int nhwc_geom(const char* name, NhwcGeom& gm, int N, int C, int HW, int G, const void* p0, const void* p1, const void* p2) {
+    VFT_CHECK_ARG(C % 8 == 0 && C / 8 <= 320, "%s: channels-last path needs C %% 8 == 0 and C <= 2560 (C=%d)", name, C);
+    VFT_CHECK_ARG((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0, "%s: pointers must be 16-byte aligned", name);
+    VFT_CHECK_ARG(G * 2 * sizeof(float) <= 48 * 1024, "%s: too many groups (%d)", name, G);
+    gm.C = C;
+    gm.HW = HW;
+    gm.G = G;
+    gm.cpg = C / G;
+    gm.CV = C / 8;
+    gm.R = (256 + gm.CV / 2) / gm.CV;
+    while (gm.R > 1 && gm.CV * gm.R > 320) --gm.R;
+    if (gm.R < 1) gm.R = 1;
+    int64_t per_thread = ((int64_t)N * HW) / ((int64_t)gm.R * 2048);
+    if (per_thread < 4) per_thread = 4;
+    if (per_thread > 64) per_thread = 64;
+    gm.rows_per_block = (int)per_thread * gm.R;
+    return 0;
+}
+
 unsigned grid_for(int64_t nvec) {
     int64_t b = (nvec + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -245,5 +520,43 @@ extern "C" int vft_groupnorm_bwd(const void* x, const void* dy, const float* sta
     }
 #undef VFT_GN_BWD
     VFT_CHECK_LAUNCH("vft_groupnorm_bwd");
+    return 0;
+}
+
+// ---- channels-last (NHWC) entry points: same arguments, x / y / dy / dx are [N][HW][C] ----
+extern "C" int vft_groupnorm_nhwc_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats, int N,
+                                      int C, int HW, int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && y && stats, "vft_groupnorm_nhwc_fwd: null pointer");
+    if (gn_args("vft_groupnorm_nhwc_fwd", N, C, HW, G)) return 1;
+    NhwcGeom gm;
+    if (nhwc_geom("vft_groupnorm_nhwc_fwd", gm, N, C, HW, G, x, y, nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(float), st);
+    const dim3 grid((HW + gm.rows_per_block - 1) / gm.rows_per_block, N), block(gm.CV * gm.R);
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel, grid, block, G * 2 * sizeof(float), st, (const bf16_t*)x, stats, gm);
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel, grid, block, 0, st, (const bf16_t*)x, stats, (const bf16_t*)weight,
+                       (const bf16_t*)bias, (bf16_t*)y, gm, eps, fuse_silu);
+    VFT_CHECK_LAUNCH("vft_groupnorm_nhwc_fwd");
+    return 0;
+}
+
+extern "C" int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float* stats, const void* weight,
+                                      const void* bias, void* dx, float* bstats, float* dweight, float* dbias, int N, int C,
+                                      int HW, int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && dy && stats && dx && bstats, "vft_groupnorm_nhwc_bwd: null pointer");
+    if (gn_args("vft_groupnorm_nhwc_bwd", N, C, HW, G)) return 1;
+    NhwcGeom gm;
+    if (nhwc_geom("vft_groupnorm_nhwc_bwd", gm, N, C, HW, G, x, dy, dx)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(bstats, 0, (size_t)N * G * 2 * sizeof(float), st);
+    if (dweight) hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
+    if (dbias) hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
+    const dim3 grid((HW + gm.rows_per_block - 1) / gm.rows_per_block, N), block(gm.CV * gm.R);
+    hipLaunchKernelGGL(gn_nhwc_bwd_stats_kernel, grid, block, G * 2 * sizeof(float), st, (const bf16_t*)x,
+                       (const bf16_t*)dy, stats, (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, gm, eps,
+                       fuse_silu);
+    hipLaunchKernelGGL(gn_nhwc_bwd_dx_kernel, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats,
+                       (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, gm, eps, fuse_silu);
+    VFT_CHECK_LAUNCH("vft_groupnorm_nhwc_bwd");
     return 0;
 }

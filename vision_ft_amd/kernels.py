@@ -308,37 +308,45 @@ def gate_residual(residual: torch.Tensor, gate: torch.Tensor, y: torch.Tensor, t
     return _GateResidual.apply(residual, gate, y, tanh)
 
 
+def _is_nhwc(x: torch.Tensor) -> bool:
+    """True when a (N,C,H,W) tensor is stored channels-last (and that is not also the NCHW order)."""
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, groups, eps, silu):
         N, C, H, W = x.shape
-        x = x.contiguous()
+        nhwc = _is_nhwc(x) and C % 8 == 0 and C <= 2560
+        if not nhwc:
+            x = x.contiguous()
         w, b_ = _bf16_or_none(weight), _bf16_or_none(bias)
-        y = torch.empty_like(x)
+        y = torch.empty_like(x)  # preserves the memory format
         stats = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+        fn = _C.lib().vft_groupnorm_nhwc_fwd if nhwc else _C.lib().vft_groupnorm_fwd
         with torch.cuda.device(x.device), _Timed("groupnorm_fwd", 6.0 * x.numel()):
-            st = _C.lib().vft_groupnorm_fwd(_ptr(x), _ptr(y), _ptr(w), _ptr(b_), _ptr(stats), N, C, H * W, groups,
-                                            float(eps), int(silu), _stream())
+            st = fn(_ptr(x), _ptr(y), _ptr(w), _ptr(b_), _ptr(stats), N, C, H * W, groups, float(eps), int(silu), _stream())
         _C.check(st, "vft_groupnorm_fwd")
         ctx.save_for_backward(x, w, b_, stats)
-        ctx.meta = (groups, eps, silu, weight, bias)
+        ctx.meta = (groups, eps, silu, weight, bias, nhwc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, b_, stats = ctx.saved_tensors
-        groups, eps, silu, weight, bias = ctx.meta
+        groups, eps, silu, weight, bias, nhwc = ctx.meta
         N, C, H, W = x.shape
-        dy = dy.contiguous()
+        dy = dy.contiguous(memory_format=torch.channels_last) if nhwc else dy.contiguous()
         dx = torch.empty_like(x)
         bstats = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
         need_w = ctx.needs_input_grad[1] and weight is not None
         need_b = ctx.needs_input_grad[2] and bias is not None
         dwf = torch.empty(C, dtype=torch.float32, device=x.device) if need_w else None
         dbf = torch.empty(C, dtype=torch.float32, device=x.device) if need_b else None
+        fn = _C.lib().vft_groupnorm_nhwc_bwd if nhwc else _C.lib().vft_groupnorm_bwd
         with torch.cuda.device(x.device), _Timed("groupnorm_bwd", 10.0 * x.numel()):
-            st = _C.lib().vft_groupnorm_bwd(_ptr(x), _ptr(dy), _ptr(stats), _ptr(w), _ptr(b_), _ptr(dx), _ptr(bstats),
-                                            _ptr(dwf), _ptr(dbf), N, C, H * W, groups, float(eps), int(silu), _stream())
+            st = fn(_ptr(x), _ptr(dy), _ptr(stats), _ptr(w), _ptr(b_), _ptr(dx), _ptr(bstats), _ptr(dwf), _ptr(dbf),
+                    N, C, H * W, groups, float(eps), int(silu), _stream())
         _C.check(st, "vft_groupnorm_bwd")
         dw = dwf.to(weight.dtype) if need_w else None
         db = dbf.to(bias.dtype) if need_b else None
@@ -346,7 +354,8 @@ class _GroupNorm(torch.autograd.Function):
 
 
 def group_norm(x: torch.Tensor, weight, bias, groups: int, eps: float, silu: bool = False) -> torch.Tensor:
-    """GroupNorm over NCHW (fp32 statistics) with optional fused SiLU."""
+    """GroupNorm over (N,C,H,W) in NCHW or channels-last storage (fp32 statistics), optional fused SiLU;
+    the output keeps the input's memory format."""
     _ready(x)
     _require_gpu(x)
     return _GroupNorm.apply(x, weight, bias, groups, eps, silu)
@@ -634,6 +643,25 @@ def gemm_nt(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = 
         st = _C.lib().vft_gemm_nt_bf16(_ptr(x2), _ptr(weight), _ptr(out), _ptr(bias), M, N, K, x2.stride(0),
                                        weight.stride(0), out.stride(0), _stream())
     _C.check(st, "vft_gemm_nt_bf16")
+    return out
+
+
+def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
+                 residual: torch.Tensor | None = None, ext_x: torch.Tensor | None = None,
+                 ext_w: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """y = x2 @ weight^T (+bias) (+ ext_x @ ext_w^T) (+residual) in one launch (vft_linear_fwd); no autograd."""
+    _ready(x2, weight)
+    _require_gpu(x2, weight, bias)
+    M, K = x2.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    r = ext_x.shape[1] if ext_x is not None else 0
+    with torch.cuda.device(x2.device), _Timed("linear_fwd", 2.0 * M * N * (K + r)):
+        st = _C.lib().vft_linear_fwd(_ptr(x2), _ptr(weight), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ext_x), _ptr(ext_w),
+                                     M, N, K, r, x2.stride(0), weight.stride(0), out.stride(0),
+                                     residual.stride(0) if residual is not None else 0, _stream())
+    _C.check(st, "vft_linear_fwd")
     return out
 
 

@@ -464,6 +464,27 @@ class UNet(nn.Module):
     def get_timestep_embedding(self, timestep: torch.Tensor, dim: int) -> torch.Tensor:
         return get_timestep_embedding(timestep, embedding_dim=dim, flip_sin_to_cos=True, downscale_freq_shift=0.0)
 
+    def to_channels_last(self) -> "UNet":
+        """Store every convolution weight (and its gradient view, if one exists) channels-last.
+
+        Activations then stay NHWC through the whole network: MIOpen's implicit-GEMM convolutions run
+        without layout transposes, GroupNorm uses the NHWC kernel, and the (N,C,H,W)->(N,HW,C) token
+        reshapes around each SpatialTransformer are views instead of copies.  Shapes, state-dict keys
+        and values are unchanged (memory format only).  Called once, lazily, by the first CUDA forward."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                w = m.weight
+                if w.is_contiguous(memory_format=torch.channels_last):
+                    continue
+                g = w.grad
+                w.data = w.data.contiguous(memory_format=torch.channels_last)
+                if g is not None:  # e.g. a view into the trainer's flat gradient buffer: re-stride in place
+                    vals = g.clone()
+                    w.grad = g.as_strided(w.size(), w.stride())
+                    w.grad.copy_(vals)
+        self._nhwc = True
+        return self
+
     def prepare_global_condition(self, timestep, text_pooler_output, original_size, target_size, crop_coords, dtype):
         t_emb = self.time_embed(self.get_timestep_embedding(timestep, self.hidden_dim).to(dtype))
         b = text_pooler_output.size(0)
@@ -477,6 +498,11 @@ class UNet(nn.Module):
                 crop_coords_top_left: torch.Tensor, cross_attention_kwargs: dict | None = None) -> torch.Tensor:
         dtype = module_dtype(self.out[2])
         latents = latents.to(dtype)
+        if latents.is_cuda:
+            # MI355X layout: the whole UNet runs channels-last (see to_channels_last)
+            if not getattr(self, "_nhwc", False):
+                self.to_channels_last()
+            latents = latents.contiguous(memory_format=torch.channels_last)
         context = encoder_hidden_states.to(dtype)
         t_emb, g_emb = self.prepare_global_condition(timestep, encoder_pooler_output, original_size, target_size,
                                                      crop_coords_top_left, dtype)

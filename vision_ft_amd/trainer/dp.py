@@ -34,7 +34,10 @@ class FlatGradBuffer:
             buf = torch.zeros(total, dtype=dt, device=ps[0].device)
             off = 0
             for p in ps:
-                p.grad = buf[off : off + p.numel()].view_as(p)
+                # same dense layout as the parameter (contiguous or channels-last), so fused optimizers
+                # see matching strides
+                p.grad = buf[off : off + p.numel()].as_strided(p.size(), p.stride()) if _dense(p) else \
+                    buf[off : off + p.numel()].view_as(p)
                 off += _padded(p.numel())
             self.buffers[dt] = buf
 
@@ -44,6 +47,10 @@ class FlatGradBuffer:
 
     def nbytes(self) -> int:
         return sum(b.numel() * b.element_size() for b in self.buffers.values())
+
+
+def _dense(p: torch.Tensor) -> bool:
+    return p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
 
 
 def _padded(n: int, align: int = 64) -> int:
