@@ -55,14 +55,19 @@ int vft_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                  const int64_t* o_strides, float scale, void* stream);
 
-/* Backward of the above.  delta_ws: [B,Hq,Sq] fp32 scratch.  dk/dv are per kv head (the sum over
- * the query heads of a GQA group happens in-kernel).  Deterministic (no atomics). */
+/* Backward of the above.  ws: fp32 scratch of ws_floats elements, at least B*Hq*Sq (delta = rowsum(dO*O));
+ * allocate vft_attn_bwd_workspace(...) floats to let short key sequences (cross-attention, Sk = 77:
+ * sdxl/denoiser.py:224-262) split their query tiles over more workgroups — the partial dK/dV are then
+ * summed in a fixed order.  dk/dv are per kv head (the sum over the query heads of a GQA group happens
+ * in-kernel).  Deterministic (no atomics). */
+int64_t vft_attn_bwd_workspace(int B, int Hq, int Hkv, int Sq, int Sk, int D);
 int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
-                 const float* lse, void* dq, void* dk, void* dv, float* delta_ws,
+                 const float* lse, void* dq, void* dk, void* dv, float* ws,
                  const int32_t* kv_len, int B, int Hq, int Hkv, int Sq, int Sk, int D,
                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                  const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides,
-                 const int64_t* dk_strides, const int64_t* dv_strides, float scale, void* stream);
+                 const int64_t* dk_strides, const int64_t* dv_strides, float scale, int64_t ws_floats,
+                 void* stream);
 
 /* ---- LoRA -----------------------------------------------------------------------------------
  * Replace the low-rank branch of LoRALinear.forward, src/modules/peft/lora.py:92-104

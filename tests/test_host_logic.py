@@ -199,7 +199,7 @@ def test_c_abi_exports_every_declared_symbol():
     from vision_ft_amd import _C
 
     header = open("include/vft_hip.h").read()
-    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(vft_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|size_t|const char\*)\s+(vft_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 20
     lib = _C.lib()
     for name in declared:

@@ -37,8 +37,9 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "vft_attn_bwd": (
         c_int,
-        [c_void_p] * 11 + [c_int] * 6 + [_I64P] * 8 + [c_float, c_void_p],
+        [c_void_p] * 11 + [c_int] * 6 + [_I64P] * 8 + [c_float, c_int64, c_void_p],
     ),
+    "vft_attn_bwd_workspace": (c_int64, [c_int] * 6),
     "vft_lora_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_bwd_dx": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),

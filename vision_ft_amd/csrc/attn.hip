@@ -42,6 +42,8 @@ struct AttnParams {
     float* lse;             // [B, Hq, Sq] natural-log LSE of scaled scores
     float* delta;           // [B, Hq, Sq] rowsum(dO*O)
     const int32_t* kv_len;  // [B] or nullptr
+    float* split_ws;        // bwd, nsplit > 1: fp32 partial dK | dV, each [nsplit][B*Hkv][Sk][D]
+    int nsplit;
     int B, Hq, Hkv, Sq, Sk;
     float scale;
     Str3 sq, sk, sv, so, sdo, sdq, sdk, sdv;
@@ -506,14 +508,15 @@ template <int D, int BQ>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnParams p) {
     constexpr int LD = D + 8, KS = D / 16, DT = D / 32, QT = BQ / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* dOs = Qs + BQ * LD;
-    float* lse_s = reinterpret_cast<float*>(dOs + BQ * LD);
-    float* dl_s = lse_s + BQ;
+    // two buffers of [Q tile | dO tile | lse | delta]: the next tile is written while this one is read,
+    // one barrier per tile
+    constexpr int BUFB = 2 * BQ * LD * (int)sizeof(bf16_t) + 2 * BQ * (int)sizeof(float);  // bytes per buffer
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     int ktile, bh;
-    if (!xcd_map((p.Sk + 127) / 128, p.B * p.Hkv, ktile, bh)) return;  // block-uniform
+    if (!xcd_map(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv, ktile, bh)) return;  // block-uniform
+    const int split = ktile % p.nsplit;  // split-Q: this workgroup reduces a slice of the query tiles
+    ktile /= p.nsplit;
     const int b = bh / p.Hkv, hkv = bh % p.Hkv, n0 = ktile * 128;
     const int G = p.Hq / p.Hkv;
     int kvl = p.Sk;
@@ -549,10 +552,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     TileStage<D, BQ> qst, dost;
     float lse_r = INFINITY, dl_r = 0.f;
     int cur_g = -1;
-    const bf16_t* qfrag = Qs + r * LD + 8 * h;
-    const bf16_t* dofrag = dOs + r * LD + 8 * h;
-    const bf16_t* qtr = Qs + tr_lane_off(LD, lane);
-    const bf16_t* dotr = dOs + tr_lane_off(LD, lane);
+    const int frag_off = r * LD + 8 * h;
+    const int tr_off = tr_lane_off(LD, lane);
     auto prefetch = [&](int it) {
         const int g = it / nqt, t = it % nqt;
         const int hq = hkv * G + g;
@@ -570,18 +571,40 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
             dl_r = q < p.Sq ? p.delta[srow] : 0.f;
         }
     };
-    if (niter > 0) prefetch(0);
-
-    for (int it = 0; it < niter; ++it) {
-        __syncthreads();
-        qst.store(Qs);
-        dost.store(dOs);
+    auto stash = [&](int buf) {
+        char* base = smem + buf * BUFB;
+        bf16_t* Qn = reinterpret_cast<bf16_t*>(base);
+        qst.store(Qn);
+        dost.store(Qn + BQ * LD);
         if (tid < BQ) {
-            lse_s[tid] = lse_r;
-            dl_s[tid] = dl_r;
+            float* ls = reinterpret_cast<float*>(base + 2 * BQ * LD * sizeof(bf16_t));
+            ls[tid] = lse_r;
+            ls[BQ + tid] = dl_r;
         }
-        __syncthreads();
-        if (it + 1 < niter) prefetch(it + 1);
+    };
+    const int per_split = (niter + p.nsplit - 1) / p.nsplit;
+    const int it0 = split * per_split, it1 = min(niter, it0 + per_split);
+    if (it0 < it1) {
+        prefetch(it0);
+        stash(0);
+    }
+    __syncthreads();
+    if (it0 + 1 < it1) prefetch(it0 + 1);
+
+    for (int it = it0; it < it1; ++it) {
+        const char* base = smem + ((it - it0) & 1) * BUFB;
+        const bf16_t* Qs = reinterpret_cast<const bf16_t*>(base);
+        const bf16_t* dOs = Qs + BQ * LD;
+        const float* lse_s = reinterpret_cast<const float*>(base + 2 * BQ * LD * sizeof(bf16_t));
+        const float* dl_s = lse_s + BQ;
+        const bf16_t* qfrag = Qs + frag_off;
+        const bf16_t* dofrag = dOs + frag_off;
+        const bf16_t* qtr = Qs + tr_off;
+        const bf16_t* dotr = dOs + tr_off;
+        if (it + 1 < it1) {  // the other buffer was last read before the barrier that ended tile it-1
+            stash((it + 1 - it0) & 1);
+            if (it + 2 < it1) prefetch(it + 2);
+        }
 
         bf16x8 Pf[2 * QT], dSf[2 * QT];
 #pragma unroll
@@ -626,6 +649,30 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
                 bf16x8 c = tr_frag(qtr, LD, kk * 16, dt * 32);
                 dK[dt] = mfma32(c, dSf[kk], dK[dt]);
             }
+        __syncthreads();
+    }
+    if (p.nsplit > 1) {
+        // fp32 partials, summed in a fixed order by attn_bwd_split_reduce_kernel (deterministic)
+        if (kmem) {
+            const int64_t plane = (int64_t)p.B * p.Hkv * p.Sk * D;
+            float* wk = p.split_ws + (((int64_t)split * p.B * p.Hkv + bh) * p.Sk + key) * D;
+            float* wv = wk + (int64_t)p.nsplit * plane;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * h;
+                    f32x4 a, c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = dK[dt][4 * g + i];
+                        c[i] = dV[dt][4 * g + i];
+                    }
+                    *reinterpret_cast<f32x4*>(wk + d) = a;
+                    *reinterpret_cast<f32x4*>(wv + d) = c;
+                }
+        }
+        return;
     }
     if (kmem) {
         const float s = p.scale;
@@ -640,6 +687,46 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
                        dV[dt][4 * g + 3]);
             }
     }
+}
+
+// dk / dv = Σ_split partial (fixed order), dk scaled; one thread = 4 consecutive d of one key
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_split_reduce_kernel(AttnParams p) {
+    const int64_t rows = (int64_t)p.B * p.Hkv * p.Sk;
+    const int64_t plane = rows * D;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * (D / 4)) return;
+    const int64_t row = e / (D / 4);
+    const int d = (int)(e % (D / 4)) * 4;
+    const int key = (int)(row % p.Sk);
+    const int bh = (int)(row / p.Sk), b = bh / p.Hkv, hkv = bh % p.Hkv;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float* wk = p.split_ws + (int64_t)s * plane + row * D + d;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(wk);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(wk + (int64_t)p.nsplit * plane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] += x[i];
+            c[i] += y[i];
+        }
+    }
+    store4(p.dk + b * p.sdk.b + hkv * p.sdk.h + (int64_t)key * p.sdk.s + d, a[0] * p.scale, a[1] * p.scale, a[2] * p.scale,
+           a[3] * p.scale);
+    store4(p.dv + b * p.sdv.b + hkv * p.sdv.h + (int64_t)key * p.sdv.s + d, c[0], c[1], c[2], c[3]);
+}
+
+// Short key sequences (cross-attention: 77 text tokens) give the dK/dV kernel one workgroup per (batch, head)
+// — far fewer than 256 CUs — each walking every query tile.  Split the query tiles over `nsplit` workgroups.
+__host__ inline int dkdv_nsplit(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
+    const int BQ = D == 256 ? 32 : 64;
+    const int64_t blocks = (int64_t)((Sk + 127) / 128) * B * Hkv;
+    const int64_t niter = (int64_t)(Hq / Hkv) * ((Sq + BQ - 1) / BQ);
+    if (blocks >= 256) return 1;
+    int64_t ns = (512 + blocks - 1) / blocks;
+    if (ns > niter / 4) ns = niter / 4;
+    if (ns > 32) ns = 32;
+    return ns < 1 ? 1 : (int)ns;
 }
 
 int check_strides(const char* name, const int64_t* s) {
@@ -703,16 +790,21 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
         VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
     {
-        constexpr size_t lds = 2 * BQ * (D + 8) * sizeof(bf16_t) + 2 * BQ * sizeof(float);
+        constexpr size_t lds = 2 * (2 * BQ * (D + 8) * sizeof(bf16_t) + 2 * BQ * sizeof(float));  // double-buffered
         static bool attr = false;
         if (!attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<D, BQ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        dim3 grid(xcd_grid((p.Sk + 127) / 128, p.B * p.Hkv));
+        dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, BQ>), grid, dim3(256), lds, st, p);
         VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
+        if (p.nsplit > 1) {
+            const int64_t n = (int64_t)p.B * p.Hkv * p.Sk * (D / 4);
+            hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(split reduce)");
+        }
     }
     return 0;
 }
@@ -747,12 +839,20 @@ extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* o
     }
 }
 
+// floats the caller should allocate for vft_attn_bwd's workspace: delta, plus split-Q partials when they pay
+extern "C" int64_t vft_attn_bwd_workspace(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return 0;
+    const int64_t delta_floats = ((int64_t)B * Hq * Sq + 3) / 4 * 4;
+    const int ns = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
+    return delta_floats + (ns > 1 ? 2 * (int64_t)ns * B * Hkv * Sk * D : 0);
+}
+
 extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                             const float* lse, void* dq, void* dk, void* dv, float* delta_ws, const int32_t* kv_len,
                             int B, int Hq, int Hkv, int Sq, int Sk, int D, const int64_t* q_strides,
                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
                             const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                            const int64_t* dv_strides, float scale, void* stream) {
+                            const int64_t* dv_strides, float scale, int64_t ws_floats, void* stream) {
     if (check_dims(B, Hq, Hkv, Sq, Sk, D)) return 1;
     if (check_ptr("q", q) || check_ptr("k", k) || check_ptr("v", v) || check_ptr("out", out) ||
         check_ptr("dout", dout) || check_ptr("dq", dq) || check_ptr("dk", dk) || check_ptr("dv", dv))
@@ -778,6 +878,12 @@ extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const v
     p.scale = scale;
     p.sq = mk(q_strides), p.sk = mk(k_strides), p.sv = mk(v_strides), p.so = mk(o_strides);
     p.sdo = mk(do_strides), p.sdq = mk(dq_strides), p.sdk = mk(dk_strides), p.sdv = mk(dv_strides);
+    // workspace = delta [B*Hq*Sq] followed (16-byte aligned) by the split-Q partials when the caller provided room
+    const int64_t delta_floats = ((int64_t)B * Hq * Sq + 3) / 4 * 4;
+    VFT_CHECK_ARG(ws_floats >= (int64_t)B * Hq * Sq, "vft_attn_bwd: workspace too small (%lld floats)", (long long)ws_floats);
+    p.nsplit = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
+    if (p.nsplit > 1 && ws_floats < delta_floats + 2 * (int64_t)p.nsplit * B * Hkv * Sk * D) p.nsplit = 1;
+    p.split_ws = delta_ws + delta_floats;
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
         case 64: return launch_bwd<64, 64>(p, st);

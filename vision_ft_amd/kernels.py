@@ -129,7 +129,8 @@ class _FlashAttention(torch.autograd.Function):
         dq = _empty_bshd_as_bhsd(B, Hq, Sq, D, q)
         dk = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
         dv = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
-        delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+        ws_floats = int(_C.lib().vft_attn_bwd_workspace(B, Hq, Hkv, Sq, Sk, D))
+        delta = torch.empty(ws_floats, dtype=torch.float32, device=q.device)  # delta (+ split-Q partials)
         with torch.cuda.device(q.device), _Timed(f"attn_bwd_d{D}", 10.0 * B * Hq * Sq * Sk * D):
             st = _C.lib().vft_attn_bwd(
                 _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
@@ -137,7 +138,7 @@ class _FlashAttention(torch.autograd.Function):
                 B, Hq, Hkv, Sq, Sk, D,
                 _C.i64x3(q.stride()[:3]), _C.i64x3(k.stride()[:3]), _C.i64x3(v.stride()[:3]),
                 _C.i64x3(out.stride()[:3]), _C.i64x3(dout.stride()[:3]), _C.i64x3(dq.stride()[:3]),
-                _C.i64x3(dk.stride()[:3]), _C.i64x3(dv.stride()[:3]), ctx.scale, _stream(),
+                _C.i64x3(dk.stride()[:3]), _C.i64x3(dv.stride()[:3]), ctx.scale, ws_floats, _stream(),
             )
         _C.check(st, "vft_attn_bwd")
         return dq, dk, dv, None, None
