@@ -157,6 +157,15 @@ int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void*
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,
                       int C, int rows_per_batch, int use_tanh, void* stream);
 
+/* ---- 3x3 convolution (stride 1, padding 1), channels-last, implicit GEMM ------------------------------
+ * y[B,H,W,Cout] = conv3x3(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias.  w is the storage of a channels-last
+ * nn.Conv2d weight.  Replaces the 3x3 convolutions of the SDXL ResidualBlock / Upsample
+ * (sdxl/denoiser.py:466-551); the data gradient is the same call with w' [Cin,3,3,Cout] = w flipped in
+ * (kh,kw) and transposed.  Cin % 32 == 0, Cout % 8 == 0, 16-byte aligned dense tensors.
+ */
+int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void* bias, int B, int H, int W, int Cin,
+                    int Cout, void* stream);
+
 /* ---- fused linear layer (bf16 weight) ----------------------------------------------------------
  * y[M,N] = x[M,K] . w[N,K]^T (+ bias[N]) (+ ext_x[M,r] . ext_w[N,r]^T) (+ residual[M,N])
  * One launch for the reference's LoRALinear.forward (peft/lora.py:92-104: linear(x) + lora_up(lora_down(x)) * s):

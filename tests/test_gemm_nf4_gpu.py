@@ -210,3 +210,45 @@ def test_linear_fused_rejects_bad_arguments(gpu):
     x, w = _bf(g, 64, 64).to(gpu), _bf(g, 64, 64).to(gpu)
     with pytest.raises(ValueError):
         kernels.linear_fused(x, w, ext_x=_bf(g, 64, 5).to(gpu), ext_w=_bf(g, 64, 5).to(gpu))  # unsupported rank
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(2, 320, 320, 32, 32, True), (1, 640, 320, 17, 23, True),
+                                                 (3, 64, 1280, 8, 8, False), (1, 1280, 1280, 16, 16, True),
+                                                 (2, 960, 320, 9, 40, True), (1, 32, 32, 1, 1, True),
+                                                 (1, 2560, 1280, 6, 6, True)])
+def test_conv3x3_implicit_gemm(gpu, B, Cin, Cout, H, W, bias):
+    """vft_conv3x3_fwd (forward and data gradient through the same kernel) vs fp32 F.conv2d; weight / bias
+    gradients (MIOpen path of the full fine-tune) are checked too."""
+    import torch.nn.functional as F
+
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(11)
+    x = _bf(g, B, Cin, H, W)
+    w = _bf(g, Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5)
+    b = _bf(g, Cout, sc=0.2) if bias else None
+    gy = _bf(g, B, Cout, H, W)
+    xg = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = b.to(gpu).requires_grad_(True) if bias else None
+    assert kernels.conv3x3_eligible(xg, wg, (1, 1), (1, 1), (1, 1), 1)
+    y = kernels.conv3x3(xg, wg, bg)
+    assert y.shape == (B, Cout, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(gpu))
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    br = b.float().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yr.backward(gy.float())
+    assert rel_err(y.cpu(), yr) < 5e-3, rel_err(y.cpu(), yr)
+    assert rel_err(xg.grad.cpu(), xr.grad) < 5e-3, rel_err(xg.grad.cpu(), xr.grad)
+    assert rel_err(wg.grad.cpu(), wr.grad) < 8e-3, rel_err(wg.grad.cpu(), wr.grad)
+    if bias:
+        assert rel_err(bg.grad.cpu(), br.grad) < 8e-3
+
+    # frozen weight (LoRA runs): cached flipped/transposed weight, no weight gradient
+    wf = w.to(gpu).contiguous(memory_format=torch.channels_last)
+    xg2 = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    for _ in range(2):
+        xg2.grad = None
+        kernels.conv3x3(xg2, wf, bg.detach() if bias else None).backward(gy.to(gpu))
+        assert rel_err(xg2.grad.cpu(), xr.grad) < 5e-3

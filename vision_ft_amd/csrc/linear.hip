@@ -42,7 +42,11 @@ struct LinParams {
     const bf16_t* ew;    // [N][r]
     int M, N, K, r;
     int64_t ldx, ldw, ldy, ldres;
+    int cH, cW, cC;      // CONV mode: image height / width / input channels (x is [B*H*W][ldx], K = 9 * cC)
 };
+
+// source of the zero padding in CONV mode (an LDS-DMA cannot skip lanes: masked lanes would leave stale data)
+__device__ __attribute__((aligned(16))) bf16_t g_zero_page[32];
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -83,8 +87,9 @@ __device__ __forceinline__ void wait_vm() {
 //   <256, 256, 2>  wave tile 128(M) x 64(N): 12 fragment reads, 4 DMAs, 16 MFMAs per K-step   (wide N)
 //   <256, 128, 4>  wave tile  64(M) x 64(N):  8 fragment reads, 3 DMAs,  8 MFMAs per K-step   (narrow N)
 constexpr int KS = 32;
-template <int BM_, int BN_, int WAVES_M_, int NSTAGE_, int WAVES_PER_SIMD_, bool DMA_IN_M_>
+template <int BM_, int BN_, int WAVES_M_, int NSTAGE_, int WAVES_PER_SIMD_, bool DMA_IN_M_, bool CONV_ = false>
 struct Cfg {
+    static constexpr bool CONV = CONV_;
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = 8 / WAVES_M_, NSTAGE = NSTAGE_;
     static constexpr int WAVES_PER_SIMD = WAVES_PER_SIMD_;
     static constexpr bool DMA_IN_M = DMA_IN_M_;
@@ -138,13 +143,27 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     //      the image is lane-linear, the bank swizzle sits on the source chunk: chunk = slot ^ ((row>>2)&3)
     const bf16_t* ga[C::DMA_A];
     const bf16_t* gb[C::DMA_B];
+    const bf16_t* gz[C::DMA_A];  // CONV only
+    unsigned vmask[C::DMA_A];    // CONV only
     {
         const int lrow = lane >> 2, slot = lane & 3;
 #pragma unroll
         for (int q = 0; q < C::DMA_A; ++q) {
             const int row = (wv * C::DMA_A + q) * 16 + lrow;
             const int ch = slot ^ ((row >> 2) & 3);
-            ga[q] = p.x + (int64_t)min(m0 + row, p.M - 1) * p.ldx + ch * 8;
+            const int pm = min(m0 + row, p.M - 1);
+            ga[q] = p.x + (int64_t)pm * p.ldx + ch * 8;
+            if (C::CONV) {  // which of the 9 taps fall inside the image for this output pixel
+                const int rem = pm % (p.cH * p.cW), oh = rem / p.cW, ow = rem - oh * p.cW;
+                unsigned m = 0;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+                    if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW) m |= 1u << tap;
+                }
+                vmask[q] = m;
+                gz[q] = g_zero_page + ch * 8;
+            }
         }
 #pragma unroll
         for (int q = 0; q < C::DMA_B; ++q) {
@@ -154,11 +173,26 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
         }
     }
     constexpr int NSTAGE = C::NSTAGE;
+    // CONV: K index = tap * Cin + c (the channels-last weight layout); K-steps are issued in increasing order,
+    // so the (tap, channel offset) of the next step is tracked incrementally
+    int ctap = 0, cc0 = 0;
     auto issue = [&](int t, int slot) {
         bf16_t* st = smem + slot * STAGE;
         const int k0 = t * KS;
+        if (C::CONV) {
+            const int64_t off = (int64_t)((ctap / 3 - 1) * p.cW + (ctap % 3 - 1)) * p.ldx + cc0;
 #pragma unroll
-        for (int q = 0; q < C::DMA_A; ++q) glds16(ga[q] + k0, st + (wv * C::DMA_A + q) * 16 * KS);
+            for (int q = 0; q < C::DMA_A; ++q)
+                glds16(((vmask[q] >> ctap) & 1u) ? ga[q] + off : gz[q], st + (wv * C::DMA_A + q) * 16 * KS);
+            cc0 += KS;
+            if (cc0 == p.cC) {
+                cc0 = 0;
+                ++ctap;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < C::DMA_A; ++q) glds16(ga[q] + k0, st + (wv * C::DMA_A + q) * 16 * KS);
+        }
 #pragma unroll
         for (int q = 0; q < C::DMA_B; ++q) glds16(gb[q] + k0, st + A_STAGE + (wv * C::DMA_B + q) * 16 * KS);
     };
@@ -336,5 +370,33 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
     else
         launch_linear<Cfg<256, 128, 4, 3, 4, false>>(p, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_linear_fwd");
+    return 0;
+}
+
+// 3x3 convolution, stride 1, padding 1, channels-last, as an implicit GEMM on the kernel above:
+//   y[b,oh,ow,:] = bias + Σ_{kh,kw} x[b,oh+kh-1,ow+kw-1,:] · w[:,kh,kw,:]ᵀ
+// M = B*H*W output pixels, N = Cout, K = 9*Cin with k = (kh*3+kw)*Cin + c, i.e. the weight exactly as a
+// channels-last nn.Conv2d stores it ([Cout][3][3][Cin]).  The activation operand is gathered by the LDS-DMA
+// source addresses (one shifted pixel row per tap; out-of-image taps read a zero page).  Replaces the cuDNN /
+// MIOpen convolutions of the SDXL ResidualBlock and Upsample (src/models/sdxl/denoiser.py:466-551); the data
+// gradient is the same call on the flipped, transposed weight.
+extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void* bias, int B, int H, int W, int Cin,
+                               int Cout, void* stream) {
+    VFT_CHECK_ARG(x && w && y, "vft_conv3x3_fwd: null pointer");
+    VFT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vft_conv3x3_fwd: non-positive dimension");
+    VFT_CHECK_ARG(Cin % KS == 0 && Cout % 8 == 0, "vft_conv3x3_fwd: needs Cin %% 32 == 0 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    VFT_CHECK_ARG((int64_t)B * H * W < (1LL << 31), "vft_conv3x3_fwd: too many pixels");
+    VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "vft_conv3x3_fwd: pointers must be 16-byte aligned");
+    VFT_CHECK_ARG(bias == nullptr || ((uintptr_t)bias & 7) == 0, "vft_conv3x3_fwd: misaligned bias");
+    LinParams p{};
+    p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y, p.bias = (const bf16_t*)bias;
+    p.M = B * H * W, p.N = Cout, p.K = 9 * Cin, p.r = 0, p.ldx = Cin, p.ldw = 9 * (int64_t)Cin, p.ldy = Cout, p.ldres = 0;
+    p.cH = H, p.cW = W, p.cC = Cin;
+    const int rem = Cout % 256;
+    if (Cout >= 1024 && (rem == 0 || rem > 192))
+        launch_linear<Cfg<256, 256, 2, 4, 2, true, true>>(p, (hipStream_t)stream);
+    else
+        launch_linear<Cfg<256, 128, 4, 3, 4, false, true>>(p, (hipStream_t)stream);
+    VFT_CHECK_LAUNCH("vft_conv3x3_fwd");
     return 0;
 }

@@ -666,6 +666,81 @@ def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
     return out
 
 
+# =============================================================================================
+# 3x3 convolution (implicit GEMM on the fused-linear kernel), channels-last
+# =============================================================================================
+def conv3x3_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:
+    """True when `kernels.conv3x3` can run this nn.Conv2d call (everything else stays on MIOpen)."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0
+            and x.shape[0] * x.shape[2] * x.shape[3] < 2**31)
+
+
+def _conv3x3_call(x_nhwc: torch.Tensor, w_ohwi: torch.Tensor, bias, B, H, W, Cin, Cout, tag: str) -> torch.Tensor:
+    y = torch.empty((B, Cout, H, W), dtype=torch.bfloat16, device=x_nhwc.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x_nhwc.device), _Timed(tag, 18.0 * B * H * W * Cin * Cout):
+        st = _C.lib().vft_conv3x3_fwd(_ptr(x_nhwc), _ptr(w_ohwi), _ptr(y), _ptr(bias), B, H, W, Cin, Cout, _stream())
+    _C.check(st, "vft_conv3x3_fwd")
+    return y
+
+
+_DGRAD_W: dict = {}  # id(weight) -> (version, data_ptr, flipped/transposed copy) for frozen weights
+
+
+def _dgrad_weight(weight: torch.Tensor) -> torch.Tensor:
+    """w'[Cin,3,3,Cout] (storage of a channels-last (Cin,Cout,3,3) tensor) = w[Cout,2-kh,2-kw,Cin]."""
+    def make():
+        return weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+
+    if weight.requires_grad:  # full fine-tune: the weight changes every step
+        return make()
+    key = id(weight)
+    hit = _DGRAD_W.get(key)
+    if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
+        hit = (weight._version, weight.data_ptr(), make())
+        if not torch.cuda.is_current_stream_capturing():  # a captured tensor lives in the graph's private pool
+            _DGRAD_W[key] = hit
+    return hit[2]
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = weight.contiguous(memory_format=torch.channels_last)
+        b_ = _bf16_or_none(bias)
+        y = _conv3x3_call(x, w, b_, B, H, W, Cin, Cout, "conv3x3_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv3x3_call(dy, _dgrad_weight(weight), None, B, H, W, Cout, Cin, "conv3x3_dgrad")
+        need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w or need_b:  # weight gradient (full fine-tune only): MIOpen
+            _, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [False, bool(need_w), bool(need_b)])
+        return dx, dw, db
+
+
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """3x3 / stride 1 / padding 1 convolution of a (B,Cin,H,W) tensor, channels-last in and out."""
+    _ready(x, weight)
+    _require_gpu(x, weight, bias)
+    return _Conv3x3.apply(x, weight, bias)
+
+
 class NF4State:
     """Device-side quantisation state of one NF4 weight (bitsandbytes layout, see modules/quant/nf4.py)."""
 

@@ -146,6 +146,17 @@ class TransformerBlock(nn.Module):
         return x
 
 
+class _Conv2d(nn.Conv2d):
+    """nn.Conv2d parameters; 3x3 / stride 1 / padding 1 convolutions run the implicit-GEMM HIP kernel
+    (forward and data gradient), everything else (the 4-channel stem / head, stride-2 downsamples, 1x1 skips)
+    stays on MIOpen."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if kernels.conv3x3_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            return kernels.conv3x3(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class _GN(nn.GroupNorm):
     """nn.GroupNorm parameters; fused GroupNorm(+SiLU) kernel."""
 
@@ -196,7 +207,7 @@ class Downsample(nn.Module):
         self.hidden_dim = hidden_dim
         self.out_channels = out_channels
         self.use_resample = use_resample
-        self.op = (nn.Conv2d(hidden_dim, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.op = (_Conv2d(hidden_dim, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
                    if use_resample else nn.AvgPool2d(kernel_size=stride, stride=stride))
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -211,7 +222,7 @@ class Upsample(nn.Module):
         self.hidden_dim = hidden_dim
         self.out_channels = out_channels
         self.scale_factor = scale_factor
-        self.conv = (nn.Conv2d(hidden_dim, out_channels, kernel_size=kernel_size, padding=padding)
+        self.conv = (_Conv2d(hidden_dim, out_channels, kernel_size=kernel_size, padding=padding)
                      if use_resample else nn.Identity())
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
@@ -253,15 +264,15 @@ class ResidualBlock(nn.Module):
         pad = kernel_size // 2
         gn_in = _GN(num_norm_groups, hidden_dim, eps=1e-5, affine=True)
         gn_in.fuse_silu = True
-        self.in_layers = nn.Sequential(gn_in, nn.SiLU(), nn.Conv2d(hidden_dim, out_channels, kernel_size, padding=pad))
+        self.in_layers = nn.Sequential(gn_in, nn.SiLU(), _Conv2d(hidden_dim, out_channels, kernel_size, padding=pad))
         self.h_upd = updown_layer(hidden_dim, out_channels, updown_type, use_resample=False)
         self.x_upd = updown_layer(hidden_dim, out_channels, updown_type, use_resample=False)
         self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(embedding_dim, out_channels))
         gn_out = _GN(num_norm_groups, out_channels, eps=1e-5, affine=True)
         gn_out.fuse_silu = True
         self.out_layers = nn.Sequential(gn_out, nn.SiLU(), nn.Dropout(dropout),
-                                        nn.Conv2d(out_channels, out_channels, kernel_size, padding=pad))
-        self.skip_connection = (nn.Conv2d(hidden_dim, out_channels, kernel_size=1, padding=0)
+                                        _Conv2d(out_channels, out_channels, kernel_size, padding=pad))
+        self.skip_connection = (_Conv2d(hidden_dim, out_channels, kernel_size=1, padding=0)
                                 if hidden_dim != out_channels else nn.Identity())
 
     def forward(self, hidden_states: torch.Tensor, embedding: torch.Tensor) -> torch.Tensor:
@@ -318,7 +329,7 @@ class DownBlocks(nn.Module):
         last = len(down_blocks) - 1
         for i, (kind, out_ch, n_tf) in enumerate(zip(down_blocks, block_out_channels, num_transformers_per_block, strict=True)):
             if kind == "DownBlock2D":
-                self.blocks.append(nn.ModuleList([nn.Conv2d(in_channels, block_out_channels[0], kernel_size=3, padding=1)]))
+                self.blocks.append(nn.ModuleList([_Conv2d(in_channels, block_out_channels[0], kernel_size=3, padding=1)]))
                 width = out_ch
                 for _ in range(layers_per_block):
                     self.blocks.append(nn.ModuleList([ResidualBlock(width, time_embed_dim, dropout, out_channels=out_ch, updown_type="none")]))
@@ -459,7 +470,7 @@ class UNet(nn.Module):
                                       attn_implementation=attn_implementation, **common)
         gn = _GN(32, hidden_dim, eps=1e-5, affine=True)
         gn.fuse_silu = True
-        self.out = nn.Sequential(gn, nn.SiLU(), nn.Conv2d(hidden_dim, out_channels, kernel_size=3, padding=1))
+        self.out = nn.Sequential(gn, nn.SiLU(), _Conv2d(hidden_dim, out_channels, kernel_size=3, padding=1))
 
     def get_timestep_embedding(self, timestep: torch.Tensor, dim: int) -> torch.Tensor:
         return get_timestep_embedding(timestep, embedding_dim=dim, flip_sin_to_cos=True, downscale_freq_shift=0.0)
