@@ -326,10 +326,11 @@ __global__ __launch_bounds__(320) void gn_nhwc_bwd_stats_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                                 float* __restrict__ bstats, float* __restrict__ dw,
                                                                 float* __restrict__ db, NhwcGeom gm, float eps, int silu) {
-    extern __shared__ float gacc[];  // [G*2]
+    extern __shared__ float gacc[];  // [G*2] (+ [2][C] when the affine gradients are wanted)
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
-    for (int i = tid; i < gm.G * 2; i += blockDim.x) gacc[i] = 0.f;
+    const int nacc = gm.G * 2 + ((dw != nullptr || db != nullptr) ? 2 * gm.C : 0);
+    for (int i = tid; i < nacc; i += blockDim.x) gacc[i] = 0.f;
     __syncthreads();
     const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
     ChanConst k;
@@ -362,11 +363,13 @@ __global__ __launch_bounds__(320) void gn_nhwc_bwd_stats_kernel(const bf16_t* __
             }
         }
     }
-    if (dw != nullptr || db != nullptr) {
+    const bool wgrad = dw != nullptr || db != nullptr;  // block-uniform
+    if (wgrad) {  // fold the block's row slots through LDS first: one global atomic per channel per block
+        float* cacc = gacc + gm.G * 2;  // [2][C], zeroed below before use
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (dw) atomicAdd(dw + cv * 8 + i, szx[i]);
-            if (db) atomicAdd(db + cv * 8 + i, sz[i]);
+            atomicAdd(&cacc[cv * 8 + i], szx[i]);
+            atomicAdd(&cacc[gm.C + cv * 8 + i], sz[i]);
         }
     }
 #pragma unroll
@@ -377,6 +380,13 @@ __global__ __launch_bounds__(320) void gn_nhwc_bwd_stats_kernel(const bf16_t* __
     fold_groups(gacc, cv * 8, gm.cpg, sz, szx);
     __syncthreads();
     for (int i = tid; i < gm.G * 2; i += blockDim.x) atomicAdd(bstats + (int64_t)n * gm.G * 2 + i, gacc[i]);
+    if (wgrad) {
+        const float* cacc = gacc + gm.G * 2;
+        for (int c = tid; c < gm.C; c += blockDim.x) {
+            if (dw) atomicAdd(dw + c, cacc[c]);
+            if (db) atomicAdd(db + c, cacc[gm.C + c]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(320) void gn_nhwc_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -552,7 +562,8 @@ extern "C" int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float
     if (dweight) hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
     if (dbias) hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
     const dim3 grid((HW + gm.rows_per_block - 1) / gm.rows_per_block, N), block(gm.CV * gm.R);
-    hipLaunchKernelGGL(gn_nhwc_bwd_stats_kernel, grid, block, G * 2 * sizeof(float), st, (const bf16_t*)x,
+    const size_t lds = (G * 2 + ((dweight || dbias) ? 2 * C : 0)) * sizeof(float);
+    hipLaunchKernelGGL(gn_nhwc_bwd_stats_kernel, grid, block, lds, st, (const bf16_t*)x,
                        (const bf16_t*)dy, stats, (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, gm, eps,
                        fuse_silu);
     hipLaunchKernelGGL(gn_nhwc_bwd_dx_kernel, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats,
