@@ -126,6 +126,23 @@ def cpu_baseline(threads: int) -> dict:
                       f"autocast cpu bf16): 1 warm-up + 2 timed steps, {r['s_per_step']:.2f} s/step"}
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.csv:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py, gfx950 x2 fetch
+    correction applied) — measured at the kernel's dominant bench shape, not inside this run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.csv")
+    try:
+        import csv
+
+        for row in csv.DictReader(open(path)):
+            if row["kernel"] == kernel:
+                return (round(float(row["traffic_MB"]) * 1e6),
+                        f"bytes/launch at B16 H10 S4096 D64 (the 64x64-latent self-attention); algorithmic {row['algorithmic_MB']} MB")
+    except OSError:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,9 +234,14 @@ def main():
         work = sum(prof[k]["work"] for k in fwd_keys)
         ms = sum(prof[k]["ms"] for k in fwd_keys)
         ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        n_launch = sum(prof[k]["launches"] for k in fwd_keys)
+        traffic, traffic_note = pmc_traffic("attn_fwd_kernel") if args.workload.startswith("sdxl") else (None, None)
         roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": sum(prof[k]["launches"] for k in fwd_keys) // max(prof_steps, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note,
+                    "avg_launch_us": round(1e3 * ms / max(n_launch, 1), 2),
+                    "gflop_per_launch": round(work / max(n_launch, 1) / 1e9, 2),
+                    "launches_per_step": n_launch // max(prof_steps, 1),
                     "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
                     "measured": "HIP events around each launch, " + ("eager pass after the graph-replayed timed region" if use_graph else "inside the timed region"),
                     "step_mfma_frac": round(images_s / world * F_ALG[args.workload] / PEAK_BF16_MFMA_TFLOPS, 4)}

@@ -29,3 +29,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 print("algorithmic bytes: attn_fwd q+k+v+o =", 4 * B * H * S * D * 2, " lora_fwd =", 2 * M * K + 4 * M * N,
       " lora_bwd_dx =", 2 * M * N + 4 * M * K, " lora_wgrad2 =", 2 * M * (K + N))
+
+# implicit-GEMM convolution (SDXL 320->320 at 128x128, B=16) forward + data gradient
+Bc, Ci, Co, Hc = 16, 320, 320, 128
+xc = bf(Bc, Ci, Hc, Hc).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+wc = (bf(Co, Ci, 3, 3) * 0.02).contiguous(memory_format=torch.channels_last)
+bc = bf(Co)
+gyc = bf(Bc, Co, Hc, Hc).contiguous(memory_format=torch.channels_last)
+for _ in range(3):
+    kernels.conv3x3(xc, wc, bc).backward(gyc)
+torch.cuda.synchronize()
+print("conv3x3 algorithmic bytes (x + y + w) =", 2 * Bc * Hc * Hc * (Ci + Co) + 2 * 9 * Ci * Co)

@@ -40,6 +40,8 @@ def main():
             return "gemm(hipblaslt)"
         if "igemm" in n or "Im2d2Col" in n or "Col2Im" in n or "SubTensorOp" in n or "transpose" in n.lower() or "ck::" in n or "naive_conv" in n:
             return "conv(miopen/ck)"
+        if "linear_kernel" in n:
+            return "conv3x3/linear(ours)"
         if "attn_" in n:
             return "attention(ours)"
         if "lora_" in n:
