@@ -127,6 +127,8 @@ class Trainer:
         if self.config.trainer.hip_graph and self.config.optimizer.name.endswith("AdamW") and torch.cuda.is_available():
             args.setdefault("capturable", True)
             args.setdefault("fused", True)
+            # a device-resident learning rate: LR schedulers then reach the captured optimizer kernel
+            args["lr"] = torch.tensor(float(args["lr"]), dtype=torch.float32, device=params[0].device)
         self.optimizer = get_optimizer(self.config.optimizer.name, params, **args)
         sc = self.config.scheduler
         self.scheduler = get_scheduler(self.optimizer, sc.name, **sc.args) if sc is not None else None
@@ -175,8 +177,10 @@ class Trainer:
     def training_loop(self) -> None:
         step = 0
         graphs: dict = {}
-        use_graph = (self.config.trainer.hip_graph and torch.cuda.is_available() and self.gradient_accumulation_steps == 1
+        use_graph = (self.config.trainer.hip_graph and torch.cuda.is_available()
                      and getattr(self.raw_model, "graph_safe", False))
+        ga = self.gradient_accumulation_steps
+        opt_graph = None  # shared optimizer graph when the step is split (DP or accumulation)
         for epoch in range(1, self.config.num_train_epochs + 1):
             self.raw_model.before_train_epoch()
             for batch in self.train_dataloader:
@@ -187,10 +191,15 @@ class Trainer:
                     if key not in graphs:
                         from .graph import GraphedTrainStep
 
+                        first = next(iter(graphs.values()), None)
                         graphs[key] = GraphedTrainStep(self.raw_model.train_step_static, self.optimizer, self.dp,
-                                                       after_backward=self.raw_model.after_backward)
-                    loss = graphs[key]()
-                    if self.scheduler is not None:
+                                                       after_backward=self.raw_model.after_backward, split=ga > 1 or None,
+                                                       opt_graph=opt_graph, pool=first.pool() if first is not None else None,
+                                                       loss_scale=1.0 / ga)
+                        opt_graph = graphs[key].graph_b
+                    boundary = step % ga == 0
+                    loss = graphs[key](boundary)
+                    if boundary and self.scheduler is not None:
                         self.scheduler.step()
                 else:
                     loss = self.model(batch)

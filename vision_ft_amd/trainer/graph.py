@@ -21,43 +21,96 @@ import torch
 from .dp import DataParallelGrads
 
 
+def _init_optimizer_state(optimizer: torch.optim.Optimizer, dp: DataParallelGrads) -> None:
+    """Allocate the optimizer's lazy state with a no-op step: zero gradients and zero learning rate (no update,
+    no weight decay, moments stay zero), then rewind the step counters."""
+    dp.zero_grad()
+    lrs = []
+    for g in optimizer.param_groups:
+        lrs.append(g["lr"].clone() if torch.is_tensor(g["lr"]) else g["lr"])
+        if torch.is_tensor(g["lr"]):
+            g["lr"].zero_()
+        else:
+            g["lr"] = 0.0
+    optimizer.step()
+    for g, lr in zip(optimizer.param_groups, lrs):
+        if torch.is_tensor(g["lr"]):
+            g["lr"].copy_(lr)
+        else:
+            g["lr"] = lr
+    for st in optimizer.state.values():
+        if "step" in st:
+            if torch.is_tensor(st["step"]):
+                st["step"].zero_()
+            else:
+                st["step"] = 0
+
+
+class GraphedOptimizerStep:
+    """optimizer.step() + zeroing of the flat gradient buffer as one graph (shape-independent: shared by
+    every bucket's forward/backward graph when the step is split)."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer, dp: DataParallelGrads, pool=None):
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=pool):
+            optimizer.step()
+            dp.zero_grad()
+
+    def replay(self) -> None:
+        self.graph.replay()
+
+
 class GraphedTrainStep:
+    """One bucket shape's training step as HIP graphs.
+
+    split=False (single GPU, no accumulation): forward + backward + optimizer in one graph.
+    split=True  (DP or gradient accumulation): graph A = forward + backward (gradients accumulate in the flat
+    buffer); the optimizer graph (`opt_graph`, shared between bucket shapes) is replayed only on accumulation
+    boundaries, after the all-reduce.  `pool` lets all bucket graphs share one private memory pool — they
+    never replay concurrently, so the activation memory is paid once, not once per bucket."""
+
     def __init__(self, forward_loss: Callable[[], torch.Tensor], optimizer: torch.optim.Optimizer,
-                 dp: DataParallelGrads, warmup: int = 3, after_backward: Callable[[], None] | None = None):
+                 dp: DataParallelGrads, warmup: int = 3, after_backward: Callable[[], None] | None = None,
+                 split: bool | None = None, opt_graph: GraphedOptimizerStep | None = None, pool=None,
+                 loss_scale: float = 1.0):
         self.forward_loss = forward_loss
         self.optimizer = optimizer
         self.dp = dp
         self.after_backward = after_backward
-        self.single = dp.world == 1
+        self.loss_scale = float(loss_scale)  # 1 / gradient_accumulation_steps; the reported loss stays unscaled
+        self.single = dp.world == 1 and not split
         self.loss: torch.Tensor | None = None
         self._eager(warmup)  # allocator, MIOpen find, lazy kernel attributes: everything un-capturable happens here
-        self._capture()
-
-    def _eager_once(self) -> torch.Tensor:
-        loss = self.forward_loss()
-        loss.backward()
-        if self.after_backward is not None:
-            self.after_backward()
-        self.dp.reduce_async()
-        self.dp.wait()
-        self.optimizer.step()
-        self.dp.zero_grad()
-        return loss
+        self._capture(pool, opt_graph)
 
     def _eager(self, n: int) -> None:
+        """Eager passes that leave the run exactly where it was: everything un-capturable (allocator growth,
+        MIOpen find, lazy kernel attributes, lazy optimizer state) happens here, but gradients already
+        accumulated in the flat buffer, the weights, the moments and the step counts are preserved — a graph
+        run takes the same optimizer steps as an eager run."""
+        saved = {dt: b.clone() for dt, b in self.dp.flat.buffers.items()}
+        rng = torch.cuda.get_rng_state()  # the warm-up's timestep / noise draws are not part of the run
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(n):
-                self._eager_once()
+                loss = self.forward_loss()
+                (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+                if self.after_backward is not None:
+                    self.after_backward()
+            if not any(len(st) for st in self.optimizer.state.values()):
+                _init_optimizer_state(self.optimizer, self.dp)
+            for dt, b in self.dp.flat.buffers.items():
+                b.copy_(saved[dt])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        torch.cuda.set_rng_state(rng)
 
-    def _capture(self) -> None:
+    def _capture(self, pool, opt_graph) -> None:
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, pool=pool):
             loss = self.forward_loss()
-            loss.backward()
+            (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
             if self.after_backward is not None:
                 self.after_backward()
             if self.single:
@@ -66,15 +119,17 @@ class GraphedTrainStep:
             self.loss = loss.detach()
         self.graph_b = None
         if not self.single:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-                self.optimizer.step()
-                self.dp.zero_grad()
+            self.graph_b = opt_graph if opt_graph is not None else GraphedOptimizerStep(self.optimizer, self.dp,
+                                                                                       pool=self.graph_a.pool())
 
-    def __call__(self) -> torch.Tensor:
-        """One optimizer step; returns the (device-resident, static) loss tensor of this step."""
+    def pool(self):
+        return self.graph_a.pool()
+
+    def __call__(self, boundary: bool = True) -> torch.Tensor:
+        """One micro-step (forward + backward); on an accumulation boundary also the gradient exchange and the
+        optimizer step.  Returns the (device-resident, static) loss tensor of this micro-step."""
         self.graph_a.replay()
-        if self.graph_b is not None:
+        if self.graph_b is not None and boundary:
             self.dp.reduce_async()
             self.dp.wait()
             self.graph_b.replay()
