@@ -30,7 +30,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md 
 PEAK_HBM_GBS = 8000.0
 
 # algorithmic train TFLOP per image at 1024^2 (recompute not counted)
-F_ALG = {"sdxl_lora": 13.5, "sdxl_full": 20.3, "aura_lora": 88.0, "lumina_lora": 47.6}
+F_ALG = {"sdxl_lora": 13.5, "sdxl_full": 20.3, "aura_lora": 88.0, "lumina_lora": 47.6, "lumina_qlora": 47.6,
+         "sdxl_buckets": 13.5}
 
 
 def build(workload: str, device: torch.device):
@@ -64,14 +65,26 @@ def build(workload: str, device: torch.device):
             peft = PeftTargetConfig(include_keys=["attention", "feed_forward"],
                                     exclude_keys=["text_encoder", "vae", "noise_refiner"], config=LoRAConfig(rank=4, alpha=1.0))
     model = model.to(torch.bfloat16)
-    if workload.endswith("_lora"):
+    if workload == "lumina_qlora":
+        # BASELINE config 4: the LoRA target Linears' base weights stored NF4 (blocksize 64, double-quantised
+        # absmax, bitsandbytes key layout), dequantised inside the GEMM kernel; LoRA wraps the NF4 layers
+        from vision_ft_amd.modules.quant.functional import quantize_state_dict, replace_by_prequantized_weights
+
+        sd = {k: v for k, v in model.state_dict().items()}
+        keys = [k for k in sd if k.endswith(".weight") and sd[k].dim() == 2 and ("attention" in k or "feed_forward" in k)
+                and "noise_refiner" not in k]
+        q = quantize_state_dict({k: sd[k] for k in keys}, "bnb_nf4", include_keys=keys, double_quant=True)
+        replace_by_prequantized_weights(model, q)
+        model.load_state_dict({**{k: v for k, v in sd.items() if k not in keys}, **q}, strict=True)
+        model = model.to(device)
+    if workload.endswith("lora") or workload == "sdxl_buckets":
         model.requires_grad_(False)
         peft.replace_to_peft_layer(model)
     model.train()
     return model
 
 
-def make_step(workload: str, model, device, batch: int, seed: int):
+def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int, int] = (1024, 1024)):
     from vision_ft_amd.modules.loss import diffusion as LD
     from vision_ft_amd.modules.loss import flow_match as LF
     from vision_ft_amd.modules.timestep.sampling import sigmoid_randn, uniform_rand, uniform_randint
@@ -79,8 +92,8 @@ def make_step(workload: str, model, device, batch: int, seed: int):
     g = torch.Generator(device=device).manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)  # noqa: E731
     if workload.startswith("sdxl"):
-        lat, ctx, pooled = rn(batch, 4, 128, 128), rn(batch, 77, 2048), rn(batch, 1280)
-        size = torch.tensor([[1024, 1024]] * batch, device=device)
+        lat, ctx, pooled = rn(batch, 4, wh[1] // 8, wh[0] // 8), rn(batch, 77, 2048), rn(batch, 1280)
+        size = torch.tensor([[wh[1], wh[0]]] * batch, device=device)
         crop = torch.zeros(batch, 2, dtype=torch.long, device=device)
 
         def fwd():
@@ -173,7 +186,8 @@ def main():
 
     gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
 
-    batch = args.batch or {"sdxl_lora": 16, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4}[args.workload]
+    batch = args.batch or {"sdxl_lora": 16, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4,
+                           "sdxl_buckets": 8}[args.workload]
     model = build(args.workload, device)
     params = [p for p in model.parameters() if p.requires_grad]
     dp = DataParallelGrads(params)
@@ -190,7 +204,37 @@ def main():
         dp.zero_grad()
         return loss
 
-    if use_graph:
+    imgs_per_step = batch
+    bucket_note = None
+    if args.workload == "sdxl_buckets":
+        # BASELINE config 5: mixed aspect-ratio buckets {640x1536 ... 1536x640}, one bucket per micro-batch drawn
+        # per rank from a seeded uniform multinomial, 4 micro-batches accumulated per optimizer step.  One
+        # forward/backward graph per bucket shape (shared memory pool), one shared optimizer graph.
+        from vision_ft_amd.dataset.synthetic import headline_buckets
+        from vision_ft_amd.trainer.graph import GraphedTrainStep
+
+        ga = 4
+        buckets = headline_buckets()
+        fwds = [make_step(args.workload, model, device, batch, seed=42 + rank, wh=wh) for wh in buckets]
+        graphs, opt_graph, pool = [], None, None
+        for f in fwds:
+            g_ = GraphedTrainStep(f, opt, dp, warmup=1, split=True, opt_graph=opt_graph, pool=pool, loss_scale=1.0 / ga)
+            opt_graph, pool = g_.graph_b, g_.pool()
+            graphs.append(g_)
+        draw = torch.Generator().manual_seed(1234 + rank)
+        counts = [0] * len(buckets)
+
+        def step():
+            for m in range(ga):
+                b = int(torch.randint(len(buckets), (1,), generator=draw))
+                counts[b] += 1
+                loss_ = graphs[b](boundary=m == ga - 1)
+            return loss_
+
+        imgs_per_step = batch * ga
+        bucket_note = {"buckets_wh": buckets, "grad_accum": ga, "draws": counts}
+        fwd = fwds[buckets.index((1024, 1024))]
+    elif use_graph:
         from vision_ft_amd.trainer.graph import GraphedTrainStep
 
         step = GraphedTrainStep(fwd, opt, dp, warmup=2)
@@ -228,7 +272,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        images_s = world * batch * args.steps / elapsed
+        images_s = world * imgs_per_step * args.steps / elapsed
         # roofline of the dominant hand-written kernel (attention forward): ALGORITHMIC flops / measured time
         fwd_keys = [k for k in prof if k.startswith("attn_fwd")]
         work = sum(prof[k]["work"] for k in fwd_keys)
@@ -249,9 +293,12 @@ def main():
             "metric": "train images/sec at 1024^2", "value": round(images_s, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": args.workload, "resolution": "1024x1024", "per_gpu_batch": batch,
+            "config": {"workload": args.workload, "resolution": "mixed buckets ~1 MP" if bucket_note else "1024x1024", "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph, "gemm_table": bool(gemm_table),
-                       "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5)},
+                       "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5),
+                       **({"buckets": bucket_note} if bucket_note else {}),
+                       **({"base_weights": "NF4 (blocksize 64, double-quantised absmax), dequantised in the GEMM kernel"}
+                          if args.workload == "lumina_qlora" else {})},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -83,19 +83,20 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // Tile configuration: BM x BN output tile, 8 waves as WAVES_M x WAVES_N.  K advances in steps of
-// KS = 32 (two MFMA k-steps); a ring of NSTAGE = 4 LDS stages holds K-steps t .. t+3.
+// KST (32 or 64) per LDS stage, consumed in 32-deep phases (two MFMA k-steps); a ring of NSTAGE stages.
 //   <256, 256, 2>  wave tile 128(M) x 64(N): 12 fragment reads, 4 DMAs, 16 MFMAs per K-step   (wide N)
 //   <256, 128, 4>  wave tile  64(M) x 64(N):  8 fragment reads, 3 DMAs,  8 MFMAs per K-step   (narrow N)
-constexpr int KS = 32;
-template <int BM_, int BN_, int WAVES_M_, int NSTAGE_, int WAVES_PER_SIMD_, bool DMA_IN_M_, bool CONV_ = false>
+template <int BM_, int BN_, int WAVES_M_, int NSTAGE_, int WAVES_PER_SIMD_, bool DMA_IN_M_, bool CONV_ = false, int KST_ = 32>
 struct Cfg {
     static constexpr bool CONV = CONV_;
+    static constexpr int KST = KST_;                   // K per LDS stage: 32 (64-byte rows) or 64 (full 128-byte lines)
+    static constexpr int RPD = 512 / KST_, LPR = KST_ / 8;  // rows per DMA instruction, lanes per row
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = 8 / WAVES_M_, NSTAGE = NSTAGE_;
     static constexpr int WAVES_PER_SIMD = WAVES_PER_SIMD_;
     static constexpr bool DMA_IN_M = DMA_IN_M_;
     static constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 32, FN = TN / 32;
-    static constexpr int A_STAGE = BM * KS, B_STAGE = BN * KS, STAGE = A_STAGE + B_STAGE;  // elements
-    static constexpr int DMA_A = BM / 128, DMA_B = BN / 128, DMA = DMA_A + DMA_B;          // per wave per K-step
+    static constexpr int A_STAGE = BM * KST, B_STAGE = BN * KST, STAGE = A_STAGE + B_STAGE;  // elements
+    static constexpr int DMA_A = BM / (8 * RPD), DMA_B = BN / (8 * RPD), DMA = DMA_A + DMA_B;  // per wave per stage
     static constexpr int C_LD = BN + 8, EP_ROWS = 128;                                     // epilogue image
     static constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE * sizeof(bf16_t);
     static_assert((size_t)EP_ROWS * C_LD * sizeof(bf16_t) <= LDS_BYTES, "epilogue image must fit in the stage buffers");
@@ -117,6 +118,7 @@ __device__ __forceinline__ void raw_barrier() {
 template <class C>
 __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(LinParams p) {
     constexpr int BM = C::BM, BN = C::BN, FM = C::FM, FN = C::FN, STAGE = C::STAGE, A_STAGE = C::A_STAGE;
+    constexpr int KS = C::KST, RPD = C::RPD, LPR = C::LPR;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r32 = lane & 31, h = lane >> 5;
     // waves 0-3 / 4-7 are the two phase groups; inside a group 4 waves tile WAVES_M x WAVES_N / 2 ... the
@@ -146,11 +148,11 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     const bf16_t* gz[C::DMA_A];  // CONV only
     unsigned vmask[C::DMA_A];    // CONV only
     {
-        const int lrow = lane >> 2, slot = lane & 3;
+        const int lrow = lane / LPR, slot = lane % LPR;
 #pragma unroll
         for (int q = 0; q < C::DMA_A; ++q) {
-            const int row = (wv * C::DMA_A + q) * 16 + lrow;
-            const int ch = slot ^ ((row >> 2) & 3);
+            const int row = (wv * C::DMA_A + q) * RPD + lrow;
+            const int ch = slot ^ (KS == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7));
             const int pm = min(m0 + row, p.M - 1);
             ga[q] = p.x + (int64_t)pm * p.ldx + ch * 8;
             if (C::CONV) {  // which of the 9 taps fall inside the image for this output pixel
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
         }
 #pragma unroll
         for (int q = 0; q < C::DMA_B; ++q) {
-            const int row = (wv * C::DMA_B + q) * 16 + lrow;
-            const int ch = slot ^ ((row >> 2) & 3);
+            const int row = (wv * C::DMA_B + q) * RPD + lrow;
+            const int ch = slot ^ (KS == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7));
             gb[q] = p.w + (int64_t)min(n0 + row, p.N - 1) * p.ldw + ch * 8;
         }
     }
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
             const int64_t off = (int64_t)((ctap / 3 - 1) * p.cW + (ctap % 3 - 1)) * p.ldx + cc0;
 #pragma unroll
             for (int q = 0; q < C::DMA_A; ++q)
-                glds16(((vmask[q] >> ctap) & 1u) ? ga[q] + off : gz[q], st + (wv * C::DMA_A + q) * 16 * KS);
+                glds16(((vmask[q] >> ctap) & 1u) ? ga[q] + off : gz[q], st + (wv * C::DMA_A + q) * RPD * KS);
             cc0 += KS;
             if (cc0 == p.cC) {
                 cc0 = 0;
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < C::DMA_A; ++q) glds16(ga[q] + k0, st + (wv * C::DMA_A + q) * 16 * KS);
+            for (int q = 0; q < C::DMA_A; ++q) glds16(ga[q] + k0, st + (wv * C::DMA_A + q) * RPD * KS);
         }
 #pragma unroll
-        for (int q = 0; q < C::DMA_B; ++q) glds16(gb[q] + k0, st + A_STAGE + (wv * C::DMA_B + q) * 16 * KS);
+        for (int q = 0; q < C::DMA_B; ++q) glds16(gb[q] + k0, st + A_STAGE + (wv * C::DMA_B + q) * RPD * KS);
     };
 
     f32x16 acc[FN][FM];
@@ -205,13 +207,12 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // fragment read offsets (elements): row * 32 + ((chunk ^ sw) << 3), sw = (row >> 2) & 3 = (r32 >> 2) & 3
-    const int sw = (r32 >> 2) & 3;
+    // fragment read offsets (elements): row * KS + ((chunk ^ sw) << 3); chunk = 2 * kk + h for MFMA k-step kk
+    const int sw = KS == 32 ? ((r32 >> 2) & 3) : ((r32 >> 1) & 7);
     const int xrow = (wm * C::TM + r32) * KS, wrow = A_STAGE + (wn * C::TN + r32) * KS;
-    const int co0 = ((0 + h) ^ sw) << 3, co1 = ((2 + h) ^ sw) << 3;
 
     const int nkt = p.K / KS;
-    // prologue: steps 0 .. NSTAGE-2 in flight, step 0 landed for everyone, then stagger the groups
+    // prologue: stages 0 .. NSTAGE-2 in flight, stage 0 landed for everyone, then stagger the groups
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 < nkt) issue(s0, s0);
@@ -223,46 +224,55 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     raw_barrier();
     if (grp == 1) raw_barrier();
 
-    // vmcnt that retires this wave's DMAs of step t+1 at the end of R(t): steps up to t+NSTAGE-1 (issued in
-    // R) or t+NSTAGE-2 (issued in M) are outstanding behind it
+    // vmcnt that retires this wave's DMAs of stage t+1 in the last phase of stage t: stages up to t+NSTAGE-1
+    // (issued in R) or t+NSTAGE-2 (issued in M) are outstanding behind it
     constexpr int INFLIGHT = (C::DMA_IN_M ? NSTAGE - 3 : NSTAGE - 2) * C::DMA;
-    int rs = 0;            // ring slot of step t
-    int ws = NSTAGE - 1;   // ring slot of step t + NSTAGE - 1
+    constexpr int PH = KS / 32;  // phases (32-deep) per stage
+    int rs = 0;            // ring slot of stage t
+    int ws = NSTAGE - 1;   // ring slot of stage t + NSTAGE - 1
     for (int t = 0; t < nkt; ++t) {
-        // ---- R(t) ----
         const bf16_t* st = smem + rs * STAGE;
-        bf16x8 fw[2][FN], fx[2][FM];
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            fw[0][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co0);
-            fw[1][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co1);
-        }
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            fx[0][j] = *reinterpret_cast<const bf16x8*>(st + xrow + j * 32 * KS + co0);
-            fx[1][j] = *reinterpret_cast<const bf16x8*>(st + xrow + j * 32 * KS + co1);
-        }
         const bool more = t + NSTAGE - 1 < nkt;
-        if (!C::DMA_IN_M && more) issue(t + NSTAGE - 1, ws);
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        raw_barrier();
-        // ---- M(t) ----
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ph = 0; ph < PH; ++ph) {
+            // ---- R ----
+            const int co0 = ((4 * ph + h) ^ sw) << 3, co1 = ((4 * ph + 2 + h) ^ sw) << 3;
+            bf16x8 fw[2][FN], fx[2][FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i)
+            for (int i = 0; i < FN; ++i) {
+                fw[0][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co0);
+                fw[1][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co1);
+            }
 #pragma unroll
-                for (int j = 0; j < FM; ++j) {
-                    acc[i][j] = mfma32(fw[ks][i], fx[ks][j], acc[i][j]);
-                    if (C::DMA_IN_M && ks == 0 && i == 0 && j == 0 && more) issue(t + NSTAGE - 1, ws);
+            for (int j = 0; j < FM; ++j) {
+                fx[0][j] = *reinterpret_cast<const bf16x8*>(st + xrow + j * 32 * KS + co0);
+                fx[1][j] = *reinterpret_cast<const bf16x8*>(st + xrow + j * 32 * KS + co1);
+            }
+            if (ph == 0 && !C::DMA_IN_M && more) issue(t + NSTAGE - 1, ws);
+            if (ph == PH - 1) {
+                if (more) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 }
-        __builtin_amdgcn_s_setprio(0);
-        raw_barrier();
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            raw_barrier();
+            // ---- M ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        acc[i][j] = mfma32(fw[ks][i], fx[ks][j], acc[i][j]);
+                        if (C::DMA_IN_M && ph == 0 && ks == 0 && i == 0 && j == 0 && more) issue(t + NSTAGE - 1, ws);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            raw_barrier();
+        }
         rs = rs + 1 == NSTAGE ? 0 : rs + 1;
         ws = ws + 1 == NSTAGE ? 0 : ws + 1;
     }
@@ -350,7 +360,7 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
                               int64_t ldy, int64_t ldres, void* stream) {
     VFT_CHECK_ARG(x && w && y, "vft_linear_fwd: null pointer");
     VFT_CHECK_ARG(M > 0 && N > 0 && K > 0, "vft_linear_fwd: non-positive dimension");
-    VFT_CHECK_ARG(K % KS == 0, "vft_linear_fwd: K=%d must be a multiple of %d", K, KS);
+    VFT_CHECK_ARG(K % 32 == 0, "vft_linear_fwd: K=%d must be a multiple of 32", K);
     VFT_CHECK_ARG(N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0, "vft_linear_fwd: N, ldx, ldw, ldy must be multiples of 8");
     VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "vft_linear_fwd: pointers must be 16-byte aligned");
     VFT_CHECK_ARG(bias == nullptr || ((uintptr_t)bias & 7) == 0, "vft_linear_fwd: misaligned bias");
@@ -362,10 +372,16 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y, p.bias = (const bf16_t*)bias;
     p.res = (const bf16_t*)residual, p.ex = (const bf16_t*)ext_x, p.ew = (const bf16_t*)ext_w;
     p.M = M, p.N = N, p.K = K, p.r = ext_x ? r : 0, p.ldx = ldx, p.ldw = ldw, p.ldy = ldy, p.ldres = ldres;
-    // wide tile when N fills it (>= 75 % of the last 256-wide tile column is real work); the wide tile issues
-    // its DMAs between the MFMAs (1 workgroup / CU), the narrow one in the read phase (2 workgroups / CU)
+    // wide tile when N fills it (>= 75 % of the last 256-wide tile column is real work)
+    // 64-deep stages (full 128-byte lines per DMA row) whenever K allows: 5-15 % faster than 32-deep ones
     const int rem = N % 256;
-    if (N >= 1024 && (rem == 0 || rem > 192))
+    const bool wide = N >= 1024 && (rem == 0 || rem > 192);
+    if (K % 64 == 0) {
+        if (wide)
+            launch_linear<Cfg<256, 256, 2, 2, 2, false, false, 64>>(p, (hipStream_t)stream);
+        else
+            launch_linear<Cfg<256, 128, 4, 3, 2, false, false, 64>>(p, (hipStream_t)stream);
+    } else if (wide)
         launch_linear<Cfg<256, 256, 2, 4, 2, true>>(p, (hipStream_t)stream);
     else
         launch_linear<Cfg<256, 128, 4, 3, 4, false>>(p, (hipStream_t)stream);
@@ -384,7 +400,7 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
                                int Cout, void* stream) {
     VFT_CHECK_ARG(x && w && y, "vft_conv3x3_fwd: null pointer");
     VFT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vft_conv3x3_fwd: non-positive dimension");
-    VFT_CHECK_ARG(Cin % KS == 0 && Cout % 8 == 0, "vft_conv3x3_fwd: needs Cin %% 32 == 0 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    VFT_CHECK_ARG(Cin % 32 == 0 && Cout % 8 == 0, "vft_conv3x3_fwd: needs Cin %% 32 == 0 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
     VFT_CHECK_ARG((int64_t)B * H * W < (1LL << 31), "vft_conv3x3_fwd: too many pixels");
     VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "vft_conv3x3_fwd: pointers must be 16-byte aligned");
     VFT_CHECK_ARG(bias == nullptr || ((uintptr_t)bias & 7) == 0, "vft_conv3x3_fwd: misaligned bias");
@@ -393,7 +409,13 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
     p.M = B * H * W, p.N = Cout, p.K = 9 * Cin, p.r = 0, p.ldx = Cin, p.ldw = 9 * (int64_t)Cin, p.ldy = Cout, p.ldres = 0;
     p.cH = H, p.cW = W, p.cC = Cin;
     const int rem = Cout % 256;
-    if (Cout >= 1024 && (rem == 0 || rem > 192))
+    const bool wide = Cout >= 1024 && (rem == 0 || rem > 192);
+    if (Cin % 64 == 0 && Cout >= 640) {  // (the 320-channel layers measure the same or slightly better 32-deep)
+        if (wide)
+            launch_linear<Cfg<256, 256, 2, 2, 2, false, true, 64>>(p, (hipStream_t)stream);
+        else
+            launch_linear<Cfg<256, 128, 4, 3, 2, false, true, 64>>(p, (hipStream_t)stream);
+    } else if (wide)
         launch_linear<Cfg<256, 256, 2, 4, 2, true, true>>(p, (hipStream_t)stream);
     else
         launch_linear<Cfg<256, 128, 4, 3, 4, false, true>>(p, (hipStream_t)stream);
