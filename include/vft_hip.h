@@ -157,6 +157,19 @@ int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void*
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,
                       int C, int rows_per_batch, int use_tanh, void* stream);
 
+/* ---- NF4-weight linear (QLoRA base) on the fused-linear kernel ------------------------------------------
+ * transpose_w = 0: y[M,out] = x[M,in] . W^T (+bias) (+ ext_x[M,r] . ext_w[out,r]^T) (+residual)
+ * transpose_w = 1: y[M,in]  = x[M,out] . W   (+ ext ...)   -- the data gradient
+ * W = bitsandbytes NF4 payload [out*in/2] bytes (bnb.py:37-129 layout, blocksize 64), absmax = one fp32 per
+ * 64 weights (a double-quantised checkpoint's absmax is expanded once at load time), code = the 16-entry map.
+ * Dequantisation happens in the staging threads of the GEMM; only 4-bit codes + absmax travel from HBM.
+ * in_features % 64 == 0 (and out_features % 64 == 0 for transpose_w); r in {4, 8, 16, 32}.
+ */
+int vft_linear_nf4(const void* x, void* y, const void* bias, const void* residual, const void* ext_x,
+                   const void* ext_w, const void* packed, const float* absmax, const float* code,
+                   int out_features, int in_features, int M, int r, int64_t ldx, int64_t ldy,
+                   int64_t ldres, int transpose_w, void* stream);
+
 /* ---- 3x3 convolution (stride 1, padding 1), channels-last, implicit GEMM ------------------------------
  * y[B,H,W,Cout] = conv3x3(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias.  w is the storage of a channels-last
  * nn.Conv2d weight.  Replaces the 3x3 convolutions of the SDXL ResidualBlock / Upsample

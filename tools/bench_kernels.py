@@ -106,7 +106,9 @@ def gemm():
             dy = bf(M, N)
             tq = timeit(lambda: kernels._nf4_gemm(x, st, None, False), iters=10)
             tqt = timeit(lambda: kernels._nf4_gemm(dy, st, None, True), iters=10)
-            line += f" | nf4 fwd {fl/tq/1e12:6.1f} TF/s dgrad {fl/tqt/1e12:6.1f} TF/s"
+            tq1 = timeit(lambda: kernels._nf4_gemm_v1(x, st, None, False), iters=10)
+            tqt1 = timeit(lambda: kernels._nf4_gemm_v1(dy, st, None, True), iters=10)
+            line += f" | nf4 fwd {fl/tq/1e12:6.1f} dgrad {fl/tqt/1e12:6.1f} TF/s (v1 {fl/tq1/1e12:5.1f} / {fl/tqt1/1e12:5.1f})"
         print(line)
 
 

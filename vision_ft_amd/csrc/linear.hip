@@ -42,6 +42,12 @@ struct LinParams {
     const bf16_t* ew;    // [N][r]
     int M, N, K, r;
     int64_t ldx, ldw, ldy, ldres;
+    // NF4 weight modes: logical weight [QN][QK] row-major, bitsandbytes packing (element 2i in the high nibble of
+    // byte i), one fp32 absmax per 64 consecutive elements (double-quantised absmax already expanded by the host)
+    const uint8_t* q_packed;
+    const float* q_absmax;
+    const float* q_code;  // [16]
+    int QN, QK;
     int cH, cW, cC;      // CONV mode: image height / width / input channels (x is [B*H*W][ldx], K = 9 * cC)
 };
 
@@ -77,6 +83,19 @@ __device__ __forceinline__ bf16x8 ext_frag(const bf16_t* base, int64_t row, int 
     return v;
 }
 
+// NF4 staging loads are issued as inline asm so that hipcc neither tracks them (it would drain the whole DMA
+// pipeline with vmcnt(0) at their first use) nor moves their uses above our counted wait: the wait takes the
+// destination registers as in/out operands.
+__device__ __forceinline__ void asm_load_b64(u32x2& d, const void* p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_b128(u32x4& d, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_b32(float& d, const void* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -86,9 +105,11 @@ __device__ __forceinline__ void wait_vm() {
 // KST (32 or 64) per LDS stage, consumed in 32-deep phases (two MFMA k-steps); a ring of NSTAGE stages.
 //   <256, 256, 2>  wave tile 128(M) x 64(N): 12 fragment reads, 4 DMAs, 16 MFMAs per K-step   (wide N)
 //   <256, 128, 4>  wave tile  64(M) x 64(N):  8 fragment reads, 3 DMAs,  8 MFMAs per K-step   (narrow N)
-template <int BM_, int BN_, int WAVES_M_, int NSTAGE_, int WAVES_PER_SIMD_, bool DMA_IN_M_, bool CONV_ = false, int KST_ = 32>
+template <int BM_, int BN_, int WAVES_M_, int NSTAGE_, int WAVES_PER_SIMD_, bool DMA_IN_M_, bool CONV_ = false, int KST_ = 32,
+          int WMODE_ = 0>
 struct Cfg {
     static constexpr bool CONV = CONV_;
+    static constexpr int WMODE = WMODE_;  // 0: bf16 weight by LDS-DMA; 1: NF4 as stored; 2: NF4 transposed (data gradient)
     static constexpr int KST = KST_;                   // K per LDS stage: 32 (64-byte rows) or 64 (full 128-byte lines)
     static constexpr int RPD = 512 / KST_, LPR = KST_ / 8;  // rows per DMA instruction, lanes per row
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = 8 / WAVES_M_, NSTAGE = NSTAGE_;
@@ -96,7 +117,9 @@ struct Cfg {
     static constexpr bool DMA_IN_M = DMA_IN_M_;
     static constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 32, FN = TN / 32;
     static constexpr int A_STAGE = BM * KST, B_STAGE = BN * KST, STAGE = A_STAGE + B_STAGE;  // elements
-    static constexpr int DMA_A = BM / (8 * RPD), DMA_B = BN / (8 * RPD), DMA = DMA_A + DMA_B;  // per wave per stage
+    static constexpr int DMA_A = BM / (8 * RPD), DMA_B = WMODE_ ? 0 : BN / (8 * RPD);
+    static constexpr int QW = BN / 64;                       // NF4: packed dwords per thread per stage (8 weights each)
+    static constexpr int DMA = DMA_A + (WMODE_ ? 2 : DMA_B);  // VM operations per wave per stage (NF4: codes + absmax loads)
     static constexpr int C_LD = BN + 8, EP_ROWS = 128;                                     // epilogue image
     static constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE * sizeof(bf16_t);
     static_assert((size_t)EP_ROWS * C_LD * sizeof(bf16_t) <= LDS_BYTES, "epilogue image must fit in the stage buffers");
@@ -144,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     // ---- LDS-DMA source pointers: one DMA = 16 rows x 64 B, lane -> (row = lane>>2, slot = lane&3);
     //      the image is lane-linear, the bank swizzle sits on the source chunk: chunk = slot ^ ((row>>2)&3)
     const bf16_t* ga[C::DMA_A];
-    const bf16_t* gb[C::DMA_B];
+    const bf16_t* gb[C::DMA_B ? C::DMA_B : 1];
     const bf16_t* gz[C::DMA_A];  // CONV only
     unsigned vmask[C::DMA_A];    // CONV only
     {
@@ -174,6 +197,65 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
             gb[q] = p.w + (int64_t)min(n0 + row, p.N - 1) * p.ldw + ch * 8;
         }
     }
+    // ---- NF4 weight staging (WMODE 1 / 2): packed codes + absmax -> registers -> dequantised bf16 tile in LDS ---
+    constexpr int QW = C::QW;            // packed dwords (8 weights each) per thread per 64-deep stage
+    __shared__ float2 code2_s[256];  // byte -> (code[hi nibble], code[lo nibble]): one LDS lookup per two weights
+    typedef __attribute__((ext_vector_type(QW))) unsigned int qvec_t;
+    qvec_t qreg;
+    float qam = 0.f;
+    const uint8_t* qcp = nullptr;  // this thread's packed codes at k0 = 0
+    const float* qap = nullptr;    // this thread's absmax at k0 = 0
+    int64_t qcs = 0, qas = 0;      // byte / element advance per stage
+    int qrow = 0, qseg = 0;
+    if (C::WMODE != 0) {
+        if (tid < 256) code2_s[tid] = make_float2(p.q_code[tid >> 4], p.q_code[tid & 15]);
+        if (C::WMODE == 1) {  // tile rows = weight rows n, 64 k per stage = one quantisation block per row
+            constexpr int TPR = 8 / QW;  // threads per row
+            qrow = tid / TPR, qseg = tid % TPR;
+            const int64_t e0 = (int64_t)min(n0 + qrow, p.N - 1) * p.QK + qseg * 8 * QW;
+            qcp = p.q_packed + (e0 >> 1);
+            qap = p.q_absmax + (e0 >> 6);
+            qcs = KS / 2, qas = 1;
+        } else {              // tile rows = weight columns n', stage = 64 weight rows k'
+            qrow = tid >> 3, qseg = tid & 7;
+            const int gcol = min(n0 + qseg * 8 * QW, p.QK - 8 * QW);
+            const int64_t e0 = (int64_t)qrow * p.QK + gcol;
+            qcp = p.q_packed + (e0 >> 1);
+            qap = p.q_absmax + (e0 >> 6);
+            qcs = (int64_t)KS * p.QK / 2, qas = (int64_t)KS * p.QK / 64;
+        }
+    }
+    auto nf4_store = [&](int slot) {
+        bf16_t* sb = smem + slot * STAGE + A_STAGE;
+#pragma unroll
+        for (int w = 0; w < QW; ++w) {
+            const unsigned int d = qreg[w];
+            bf16_t v[8];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const float2 c2 = code2_s[(d >> (8 * bb)) & 0xffu];
+                v[2 * bb] = (bf16_t)(c2.x * qam);
+                v[2 * bb + 1] = (bf16_t)(c2.y * qam);
+            }
+            if (C::WMODE == 1) {
+                const int chunk = qseg * QW + w;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = v[e];
+                *reinterpret_cast<bf16x8*>(sb + qrow * KS + ((chunk ^ ((qrow >> 1) & 7)) << 3)) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int nl = qseg * 8 * QW + w * 8 + e;
+                    sb[nl * KS + (((qrow >> 3) ^ ((nl >> 1) & 7)) << 3) + (qrow & 7)] = v[e];
+                }
+            }
+        }
+    };
+    auto wait_q = [&]() {  // the staging loads have landed (everything issued before them too)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(qreg), "+v"(qam) : "n"(C::DMA_A) : "memory");
+    };
+
     constexpr int NSTAGE = C::NSTAGE;
     // CONV: K index = tap * Cin + c (the channels-last weight layout); K-steps are issued in increasing order,
     // so the (tap, channel offset) of the next step is tracked incrementally
@@ -181,6 +263,13 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     auto issue = [&](int t, int slot) {
         bf16_t* st = smem + slot * STAGE;
         const int k0 = t * KS;
+        if (C::WMODE != 0) {  // before the DMAs: vmcnt(DMA_A) then retires exactly these two
+            if (QW == 2)
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qreg) : "v"(qcp + (int64_t)t * qcs) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qreg) : "v"(qcp + (int64_t)t * qcs) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(qam) : "v"(qap + (int64_t)t * qas) : "memory");
+        }
         if (C::CONV) {
             const int64_t off = (int64_t)((ctap / 3 - 1) * p.cW + (ctap % 3 - 1)) * p.ldx + cc0;
 #pragma unroll
@@ -213,10 +302,24 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
 
     const int nkt = p.K / KS;
     // prologue: stages 0 .. NSTAGE-2 in flight, stage 0 landed for everyone, then stagger the groups
+    if (C::WMODE != 0) __syncthreads();  // code2_s
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-        if (s0 < nkt) issue(s0, s0);
-    if (nkt >= NSTAGE - 1) {
+        if (s0 < nkt) {
+            issue(s0, s0);
+            if (C::WMODE != 0) {
+                wait_q();
+                nf4_store(s0);
+            }
+        }
+    if (C::WMODE != 0) {
+        // in-order retirement: only the last issued stage's DMAs can still be outstanding
+        if (NSTAGE > 2 && nkt >= NSTAGE - 1) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::DMA_A) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    } else if (nkt >= NSTAGE - 1) {
         wait_vm<(NSTAGE - 2) * C::DMA>();
     } else {
         wait_vm<0>();
@@ -226,7 +329,8 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
 
     // vmcnt that retires this wave's DMAs of stage t+1 in the last phase of stage t: stages up to t+NSTAGE-1
     // (issued in R) or t+NSTAGE-2 (issued in M) are outstanding behind it
-    constexpr int INFLIGHT = (C::DMA_IN_M ? NSTAGE - 3 : NSTAGE - 2) * C::DMA;
+    constexpr int INFLIGHT = C::WMODE != 0 ? (NSTAGE > 2 ? C::DMA_A : 0)  // (the staging-load wait already retired older stages)
+                                           : (C::DMA_IN_M ? NSTAGE - 3 : NSTAGE - 2) * C::DMA;
     constexpr int PH = KS / 32;  // phases (32-deep) per stage
     int rs = 0;            // ring slot of stage t
     int ws = NSTAGE - 1;   // ring slot of stage t + NSTAGE - 1
@@ -249,6 +353,10 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
                 fx[1][j] = *reinterpret_cast<const bf16x8*>(st + xrow + j * 32 * KS + co1);
             }
             if (ph == 0 && !C::DMA_IN_M && more) issue(t + NSTAGE - 1, ws);
+            if (C::WMODE != 0 && ph == 1 && more) {  // one phase after their issue: dequantise into the stage
+                wait_q();
+                nf4_store(ws);
+            }
             if (ph == PH - 1) {
                 if (more) {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
@@ -420,5 +528,52 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
     else
         launch_linear<Cfg<256, 128, 4, 3, 4, false, true>>(p, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_conv3x3_fwd");
+    return 0;
+}
+
+// NF4-weight linear on the same kernel: the packed 4-bit codes and one fp32 absmax per 64 weights are what travels
+// from HBM; the bf16 weight exists only as LDS tiles (dequantised by the staging threads one phase before use).
+//   transpose_w = 0:  y[M, out] = x[M, in]  . W[out, in]^T (+bias) (+ ext_x . ext_w^T) (+residual)
+//   transpose_w = 1:  y[M, in]  = x[M, out] . W[out, in]   (+ ext ...)                       (data gradient)
+// Replaces bnb.matmul_4bit of BnbLinear4bit (src/modules/quant/bnb.py:37-129) and, with the rank extension, the
+// whole NF4-base + LoRA forward of a QLoRA layer in one launch.  absmax: already expanded to fp32 by the caller
+// (double-quantised checkpoints: code2[q8] * absmax2[blk / 256] + offset, once at load time).
+extern "C" int vft_linear_nf4(const void* x, void* y, const void* bias, const void* residual, const void* ext_x,
+                              const void* ext_w, const void* packed, const float* absmax, const float* code,
+                              int out_features, int in_features, int M, int r, int64_t ldx, int64_t ldy, int64_t ldres,
+                              int transpose_w, void* stream) {
+    VFT_CHECK_ARG(x && y && packed && absmax && code, "vft_linear_nf4: null pointer");
+    const int N = transpose_w ? in_features : out_features;
+    const int K = transpose_w ? out_features : in_features;
+    VFT_CHECK_ARG(M > 0 && N > 0 && K > 0, "vft_linear_nf4: non-positive dimension");
+    VFT_CHECK_ARG(in_features % 64 == 0, "vft_linear_nf4: in_features=%d must be a multiple of 64", in_features);
+    VFT_CHECK_ARG(!transpose_w || out_features % 64 == 0, "vft_linear_nf4: transposed use needs out_features %% 64 == 0 (got %d)", out_features);
+    VFT_CHECK_ARG(N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "vft_linear_nf4: N, ldx, ldy must be multiples of 8");
+    VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)packed) & 15) == 0, "vft_linear_nf4: pointers must be 16-byte aligned");
+    VFT_CHECK_ARG(bias == nullptr || ((uintptr_t)bias & 7) == 0, "vft_linear_nf4: misaligned bias");
+    VFT_CHECK_ARG(residual == nullptr || (ldres % 8 == 0 && ((uintptr_t)residual & 15) == 0), "vft_linear_nf4: bad residual pointer / stride");
+    VFT_CHECK_ARG((ext_x == nullptr) == (ext_w == nullptr), "vft_linear_nf4: ext_x and ext_w go together");
+    VFT_CHECK_ARG(ext_x == nullptr || ((r == 4 || r == 8 || r == 16 || r == 32) && (((uintptr_t)ext_x | (uintptr_t)ext_w) & 15) == 0),
+                  "vft_linear_nf4: rank extension needs r in {4, 8, 16, 32} and 16-byte aligned operands (r=%d)", r);
+    LinParams p{};
+    p.x = (const bf16_t*)x, p.y = (bf16_t*)y, p.bias = (const bf16_t*)bias, p.res = (const bf16_t*)residual;
+    p.ex = (const bf16_t*)ext_x, p.ew = (const bf16_t*)ext_w;
+    p.M = M, p.N = N, p.K = K, p.r = ext_x ? r : 0, p.ldx = ldx, p.ldy = ldy, p.ldres = ldres;
+    p.q_packed = (const uint8_t*)packed, p.q_absmax = absmax, p.q_code = code, p.QN = out_features, p.QK = in_features;
+    const int rem = N % 256;
+    const bool wide = N >= 1024 && (rem == 0 || rem > 192) && (!transpose_w || in_features >= 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (!transpose_w) {
+        if (wide)
+            launch_linear<Cfg<256, 256, 2, 2, 2, false, false, 64, 1>>(p, st);
+        else
+            launch_linear<Cfg<256, 128, 4, 3, 2, false, false, 64, 1>>(p, st);
+    } else {
+        if (wide)
+            launch_linear<Cfg<256, 256, 2, 2, 2, false, false, 64, 2>>(p, st);
+        else
+            launch_linear<Cfg<256, 128, 4, 3, 2, false, false, 64, 2>>(p, st);
+    }
+    VFT_CHECK_LAUNCH("vft_linear_nf4");
     return 0;
 }

@@ -745,25 +745,57 @@ class NF4State:
     """Device-side quantisation state of one NF4 weight (bitsandbytes layout, see modules/quant/nf4.py)."""
 
     __slots__ = ("packed", "absmax", "absmax_is_u8", "nested_absmax", "nested_code", "code", "offset", "out_features",
-                 "in_features")
+                 "in_features", "_absmax_f32")
 
     def __init__(self, packed, absmax, nested_absmax, nested_code, code, offset, out_features, in_features):
         self.packed, self.absmax = packed, absmax
         self.absmax_is_u8 = absmax.dtype == torch.uint8
         self.nested_absmax, self.nested_code, self.code = nested_absmax, nested_code, code
         self.offset, self.out_features, self.in_features = float(offset), int(out_features), int(in_features)
+        self._absmax_f32 = None
+
+    def absmax_f32(self) -> torch.Tensor:
+        """One fp32 absmax per 64 weights; a double-quantised absmax (uint8 codes, nested fp32 absmax per 256
+        blocks, offset) is expanded once: absmax = nested_code[q8] * nested_absmax[blk // 256] + offset."""
+        if self._absmax_f32 is None:
+            if self.absmax_is_u8:
+                n = self.absmax.numel()
+                nested = self.nested_absmax.float().repeat_interleave(256)[:n]
+                self._absmax_f32 = (self.nested_code.float()[self.absmax.long()] * nested + self.offset).contiguous()
+            else:
+                self._absmax_f32 = self.absmax.float().contiguous()
+        return self._absmax_f32
 
 
-def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool) -> torch.Tensor:
+def _nf4_gemm_v1(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool) -> torch.Tensor:
+    """First-generation NF4 GEMM (vft_gemm_nf4: 128x128 register-staged tile); kept for A/B and tests."""
     M = a2.shape[0]
     N = q.in_features if transpose_w else q.out_features
     out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
     K = q.out_features if transpose_w else q.in_features
-    with torch.cuda.device(a2.device), _Timed("gemm_nf4", 2.0 * M * N * K):
+    with torch.cuda.device(a2.device), _Timed("gemm_nf4_v1", 2.0 * M * N * K):
         st = _C.lib().vft_gemm_nf4(_ptr(a2), _ptr(out), _ptr(bias), _ptr(q.packed), _ptr(q.absmax), int(q.absmax_is_u8),
                                    _ptr(q.nested_absmax), _ptr(q.nested_code), _ptr(q.code), q.offset, q.out_features,
                                    q.in_features, M, a2.stride(0), out.stride(0), int(transpose_w), _stream())
     _C.check(st, "vft_gemm_nf4")
+    return out
+
+
+def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None, ext_w=None, residual=None) -> torch.Tensor:
+    """NF4-weight GEMM on the LDS-DMA kernel (vft_linear_nf4), optional fused rank extension / residual."""
+    M = a2.shape[0]
+    N = q.in_features if transpose_w else q.out_features
+    K = q.out_features if transpose_w else q.in_features
+    if K % 64 != 0:
+        return _nf4_gemm_v1(a2, q, bias, transpose_w)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
+    r = ext_x.shape[1] if ext_x is not None else 0
+    with torch.cuda.device(a2.device), _Timed("gemm_nf4", 2.0 * M * N * (K + r)):
+        st = _C.lib().vft_linear_nf4(_ptr(a2), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ext_x), _ptr(ext_w), _ptr(q.packed),
+                                     _ptr(q.absmax_f32()), _ptr(q.code), q.out_features, q.in_features, M, r, a2.stride(0),
+                                     out.stride(0), residual.stride(0) if residual is not None else 0, int(transpose_w),
+                                     _stream())
+    _C.check(st, "vft_linear_nf4")
     return out
 
 
