@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p, int D) {
 // backward dQ: one workgroup = 128 queries, key tiles of 64
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(AttnParams p) {
     constexpr int LD = D + 8, KS = D / 16, DT = D / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
