@@ -176,10 +176,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    device = torch.device("cuda", local)
+    # (test hooks: VFT_FORCE_DEVICE / VFT_DIST_BACKEND=gloo let two ranks share one GPU to rehearse the N>1 path)
+    device = torch.device("cuda", int(os.environ.get("VFT_FORCE_DEVICE", local)))
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("VFT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from vision_ft_amd import kernels, tuning
     from vision_ft_amd.trainer.dp import DataParallelGrads
@@ -256,11 +261,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof_steps = args.steps
-    if use_graph and rank == 0:
+    if use_graph:
         # per-kernel HIP-event timing cannot be recorded inside a graph replay: time the same step
-        # eagerly (same process, same tensors) right after the timed region, outside of it
+        # eagerly (same process, same tensors) right after the timed region, outside of it.  Every rank
+        # runs it (the step contains the gradient all-reduce); only rank 0 records.
         prof_steps = 2
-        kernels.set_profiling(True)
+        kernels.set_profiling(rank == 0)
         for _ in range(prof_steps):
             eager_step()
         torch.cuda.synchronize()
