@@ -84,9 +84,11 @@ int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
  * vft_lora_wgrad2:  d_down[r,K] = scale * u^T x ;  d_up[N,r] = scale * dy^T t   (one launch pair,
  *                   deterministic two-stage reduction; workspace >= vft_lora_wgrad_workspace()).
  */
+/* residual (optional, [M][ldres]): the transformer block's `x + layer(...)` add (sdxl/denoiser.py:273-284) folded
+ * into the same pass: y = bf16(y + lora) + residual. */
 int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora_up, void* t_out,
-                 void* up_t_out, int M, int K, int N, int r, int64_t ldx, int64_t ldy, float scale,
-                 void* stream);
+                 void* up_t_out, const void* residual, int M, int K, int N, int r, int64_t ldx,
+                 int64_t ldy, int64_t ldres, float scale, void* stream);
 int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
                     int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream);
 size_t vft_lora_wgrad_workspace(int M, int K, int N, int r);
@@ -105,9 +107,10 @@ int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t,
 int vft_norm_fwd(const void* x, void* y, const void* weight, const void* bias, const void* scale,
                  const void* shift, float* mean, float* rstd, int64_t rows, int C, int64_t ldx,
                  int rows_per_batch, int kind, float eps, void* stream);
+/* dres (optional, [rows][C]): gradient arriving through the residual path around the norm; dx = norm_bwd + dres */
 int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const void* scale,
-                    const float* mean, const float* rstd, void* dx, int64_t rows, int C, int64_t ldx,
-                    int rows_per_batch, int kind, void* stream);
+                    const float* mean, const float* rstd, void* dx, const void* dres, int64_t rows, int C,
+                    int64_t ldx, int rows_per_batch, int kind, void* stream);
 
 /* ---- per-head q/k norm + RoPE ---------------------------------------------------------------
  * x: (B,S,H,D) bf16 addressed by x_strides[3] = {batch, seq, head} (so views into a fused qkv

@@ -103,3 +103,47 @@ def test_lora_wgrad_deterministic(gpu):
         kernels.lora_linear(x, lin, A, B, 0.25).float().square().mean().backward()
         outs.append((A.grad.clone(), B.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("M,K,N,r", [(1000, 640, 640, 4), (333, 2560, 640, 4), (260, 3072, 3072, 16)])
+def test_lora_linear_fused_residual_and_norm_skip(gpu, M, K, N, r):
+    """`x + lora_linear(norm(x))`-style block with the two skip fusions — the forward add inside the LoRA pass
+    (residual=...) and the backward add inside the norm-backward kernel (layer_norm_skip) — equals the plain
+    composition in fp32."""
+    import torch.nn.functional as F
+
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(3)
+    bf = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16)  # noqa: E731
+    x, W, b = bf(M, K), bf(N, K, sc=K**-0.5), bf(N, sc=0.1)
+    A, B = bf(r, K, sc=K**-0.5), bf(N, r, sc=0.3)
+    lw, lb = bf(K, sc=0.2) + 1, bf(K, sc=0.1)
+    W2 = bf(K, N, sc=N**-0.5)  # maps the block output back to K so that the skip has the input's shape
+    gy = bf(M, K)
+    s = 0.25
+
+    # fp32 reference: x1 = x + lora_linear2(lora_linear(LN(x)))  (second layer plain, carries the residual)
+    xr = x.float().requires_grad_(True)
+    Ar, Br = A.float().requires_grad_(True), B.float().requires_grad_(True)
+    n = F.layer_norm(xr, (K,), lw.float(), lb.float(), 1e-5)
+    h = n @ W.float().t() + b.float() + s * (n @ Ar.t()) @ Br.t()
+    yr = xr + h @ W2.float().t()
+    yr.backward(gy.float())
+
+    lin = torch.nn.Linear(K, N).to(gpu, torch.bfloat16).requires_grad_(False)
+    lin2 = torch.nn.Linear(N, K, bias=False).to(gpu, torch.bfloat16).requires_grad_(False)
+    with torch.no_grad():
+        lin.weight.copy_(W), lin.bias.copy_(b), lin2.weight.copy_(W2)
+    xg = x.to(gpu).requires_grad_(True)
+    Ag, Bg = A.to(gpu).requires_grad_(True), B.to(gpu).requires_grad_(True)
+    A2 = torch.zeros(r, N, device=gpu, dtype=torch.bfloat16).requires_grad_(True)   # zero adapter on the out layer:
+    B2 = torch.zeros(K, r, device=gpu, dtype=torch.bfloat16).requires_grad_(True)   # exercises residual= only
+    ng, xs = kernels.layer_norm_skip(xg, lw.to(gpu), lb.to(gpu), 1e-5)
+    hg = kernels.lora_linear(ng, lin, Ag, Bg, s)
+    yg = kernels.lora_linear(hg, lin2, A2, B2, s, residual=xs)
+    yg.backward(gy.to(gpu))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu(), yr) < 8e-3, rel_err(yg.cpu(), yr)
+    assert rel_err(xg.grad.cpu(), xr.grad) < 8e-3, rel_err(xg.grad.cpu(), xr.grad)
+    assert rel_err(Ag.grad.cpu(), Ar.grad) < 1.5e-2 and rel_err(Bg.grad.cpu(), Br.grad) < 1.5e-2

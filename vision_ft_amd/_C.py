@@ -40,12 +40,12 @@ SIGNATURES: dict[str, tuple] = {
         [c_void_p] * 11 + [c_int] * 6 + [_I64P] * 8 + [c_float, c_int64, c_void_p],
     ),
     "vft_attn_bwd_workspace": (c_int64, [c_int] * 6),
-    "vft_lora_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
+    "vft_lora_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_int64, c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_bwd_dx": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vft_lora_wgrad2": (c_int, [c_void_p] * 7 + [c_size_t] + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
     "vft_norm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
-    "vft_norm_bwd_dx": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
+    "vft_norm_bwd_dx": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "vft_qk_norm_rope_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [_I64P, c_int64, c_int, c_float, c_void_p]),
     "vft_qk_norm_rope_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [_I64P, c_int64, c_int, c_void_p]),
     "vft_groupnorm_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_int, c_void_p]),

@@ -48,6 +48,7 @@ template <int RC, bool NJ>
 __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                         const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
                                                         bf16_t* __restrict__ p_out, bf16_t* __restrict__ w2t_out,
+                                                        const bf16_t* __restrict__ res, int64_t ldres,
                                                         int M, int K, int N, int r, int64_t ldx, int64_t ldy, float s) {
     __shared__ float red[4][16][17];
     __shared__ float ps[16][17];
@@ -157,6 +158,11 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
 #pragma unroll
                         for (int j = 0; j < RC; ++j) a = fmaf(tv[j], wreg[c][j], a);
                         v[b][c] = (bf16_t)a;
+                    }
+                    if (res != nullptr && j0 + RC >= r) {  // residual add on the rounded layer output, as the reference does
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + (int64_t)(m0 + i) * ldres + n0);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[b][c] = (bf16_t)((float)v[b][c] + (float)rv[c]);
                     }
                     *reinterpret_cast<bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0) = v[b];
                 }
@@ -296,12 +302,12 @@ int chk(bool c, const char* msg) {
 }
 
 template <bool NJ>
-int launch_rows(const void* x, void* y, const void* w1, const void* w2, void* p_out, void* w2t_out, int M, int K, int N,
-                int r, int64_t ldx, int64_t ldy, float s, hipStream_t st) {
+int launch_rows(const void* x, void* y, const void* w1, const void* w2, void* p_out, void* w2t_out, const void* res,
+                int64_t ldres, int M, int K, int N, int r, int64_t ldx, int64_t ldy, float s, hipStream_t st) {
     dim3 grid((M + 15) / 16), block(256);
 #define VFT_ROWS(RC)                                                                                                  \
     hipLaunchKernelGGL((lora_rows_kernel<RC, NJ>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)w1, \
-                       (const bf16_t*)w2, (bf16_t*)p_out, (bf16_t*)w2t_out, M, K, N, r, ldx, ldy, s)
+                       (const bf16_t*)w2, (bf16_t*)p_out, (bf16_t*)w2t_out, (const bf16_t*)res, ldres, M, K, N, r, ldx, ldy, s)
     if (r <= 4)
         VFT_ROWS(4);
     else if (r <= 8)
@@ -322,12 +328,13 @@ int check_rows(const char* name, const void* x, const void* y, int M, int K, int
 }  // namespace
 
 extern "C" int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora_up, void* t_out,
-                            void* up_t_out, int M, int K, int N, int r, int64_t ldx, int64_t ldy, float scale,
-                            void* stream) {
+                            void* up_t_out, const void* residual, int M, int K, int N, int r, int64_t ldx, int64_t ldy,
+                            int64_t ldres, float scale, void* stream) {
     if (chk(x && y && lora_down && lora_up, "vft_lora_fwd: null pointer")) return 1;
     if (check_rows("vft_lora_fwd", x, y, M, K, N, r, ldx, ldy)) return 1;
     VFT_CHECK_ARG(((uintptr_t)lora_down & 15) == 0 && ((uintptr_t)up_t_out & 15) == 0, "vft_lora_fwd: lora_down / up_t_out must be 16-byte aligned");
-    launch_rows<true>(x, y, lora_down, lora_up, t_out, up_t_out, M, K, N, r, ldx, ldy, scale, (hipStream_t)stream);
+    VFT_CHECK_ARG(residual == nullptr || (ldres % 8 == 0 && ((uintptr_t)residual & 15) == 0), "vft_lora_fwd: bad residual pointer / stride");
+    launch_rows<true>(x, y, lora_down, lora_up, t_out, up_t_out, residual, ldres, M, K, N, r, ldx, ldy, scale, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_lora_fwd");
     return 0;
 }
@@ -338,7 +345,7 @@ extern "C" int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, 
     if (check_rows("vft_lora_bwd_dx", dy, dx, M, N, K, r, lddy, lddx)) return 1;
     VFT_CHECK_ARG(((uintptr_t)lora_up_t & 15) == 0 && ((uintptr_t)lora_down & 15) == 0, "vft_lora_bwd_dx: weights must be 16-byte aligned");
     // phase 1 contracts over N with Bᵀ (r,N); phase 2 streams dx (M,K) with A (r,K) in JN layout
-    launch_rows<false>(dy, dx, lora_up_t, lora_down, u_out, nullptr, M, N, K, r, lddy, lddx, scale, (hipStream_t)stream);
+    launch_rows<false>(dy, dx, lora_up_t, lora_down, u_out, nullptr, nullptr, 0, M, N, K, r, lddy, lddx, scale, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_lora_bwd_dx");
     return 0;
 }

@@ -29,6 +29,7 @@ struct NormParams {
     float* rstd;          // [rows]
     const bf16_t* dy;     // backward
     bf16_t* dx;           // backward
+    const bf16_t* dres;   // backward, optional [rows][C]: gradient arriving through the residual path, added to dx
     int64_t rows;
     int C;
     int64_t ldx;
@@ -171,6 +172,12 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(NormParams p) {
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = rstd * (g[c][i] - sg - xh[c][i] * sgx);
+            if (p.dres != nullptr) {
+                float t[8];
+                load8(p.dres + row * (int64_t)C + col, t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += t[i];
+            }
             store8(dxr + col, o);
         }
     }
@@ -360,13 +367,15 @@ extern "C" int vft_norm_fwd(const void* x, void* y, const void* weight, const vo
 }
 
 extern "C" int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const void* scale, const float* mean,
-                               const float* rstd, void* dx, int64_t rows, int C, int64_t ldx, int rows_per_batch,
-                               int kind, void* stream) {
+                               const float* rstd, void* dx, const void* dres, int64_t rows, int C, int64_t ldx,
+                               int rows_per_batch, int kind, void* stream) {
     VFT_CHECK_ARG(dy && x && dx && rstd, "vft_norm_bwd_dx: null pointer");
     VFT_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * MAXCH, "vft_norm_bwd_dx: unsupported C=%d", C);
     VFT_CHECK_ARG(kind == KIND_RMS || mean != nullptr, "vft_norm_bwd_dx: layer norm needs the saved mean");
     NormParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dx = (bf16_t*)dx, p.w = (const bf16_t*)weight;
+    p.dres = (const bf16_t*)dres;
+    VFT_CHECK_ARG(dres == nullptr || ((uintptr_t)dres & 15) == 0, "vft_norm_bwd_dx: misaligned residual gradient");
     p.scale = (const bf16_t*)scale, p.mean = const_cast<float*>(mean), p.rstd = const_cast<float*>(rstd);
     p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch, p.kind = kind;
     hipLaunchKernelGGL(norm_bwd_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);

@@ -190,7 +190,7 @@ class _RowNorm(torch.autograd.Function):
     torch ops from the saved statistics."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, kind, eps):
+    def forward(ctx, x, weight, bias, scale, shift, kind, eps, skip=False):
         C = x.shape[-1]
         x2 = _rows(x)
         rows = x2.shape[0]
@@ -205,13 +205,21 @@ class _RowNorm(torch.autograd.Function):
         _C.check(st, "vft_norm_fwd")
         ctx.save_for_backward(x2, w, b_, sc, mean, rstd)
         ctx.meta = (kind, rpb, x.shape, weight, bias, scale, shift)
+        ctx.skip = bool(skip)
+        if skip:  # (normed, x): the second output carries the residual path, so that its gradient meets the
+            return y.view(x.shape), x  # norm's own in ONE kernel instead of an autograd accumulation add
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, w, b_, sc, mean, rstd = ctx.saved_tensors
         kind, rpb, xshape, weight, bias, scale, shift = ctx.meta
         rows, C = x2.shape
+        dres = None
+        if dskip is not None:
+            dres = dskip.reshape(rows, C)
+            if dres.dtype != torch.bfloat16 or not dres.is_contiguous():
+                dres = dres.to(torch.bfloat16).contiguous()
         dy2 = dy.reshape(rows, C)
         if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
             dy2 = dy2.to(torch.bfloat16).contiguous()
@@ -220,7 +228,7 @@ class _RowNorm(torch.autograd.Function):
             dx2 = torch.empty((rows, C), dtype=torch.bfloat16, device=dy.device)
             with torch.cuda.device(dy.device), _Timed("norm_bwd", 6.0 * rows * C):
                 st = _C.lib().vft_norm_bwd_dx(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(sc), _ptr(mean), _ptr(rstd), _ptr(dx2),
-                                              rows, C, x2.stride(0), rpb, kind, _stream())
+                                              _ptr(dres), rows, C, x2.stride(0), rpb, kind, _stream())
             _C.check(st, "vft_norm_bwd_dx")
             dx = dx2.view(xshape)
         if any(ctx.needs_input_grad[1:5]):
@@ -240,13 +248,20 @@ class _RowNorm(torch.autograd.Function):
                 dsc = (g * base).view(nb, rpb, C).sum(1).to(scale.dtype).view(scale.shape)
             if ctx.needs_input_grad[4] and shift is not None:
                 dsh = g.view(nb, rpb, C).sum(1).to(shift.dtype).view(shift.shape)
-        return dx, dw, db, dsc, dsh, None, None
+        return dx, dw, db, dsc, dsh, None, None, None
 
 
-def _norm(x, weight, bias, scale, shift, kind, eps):
+def _norm(x, weight, bias, scale, shift, kind, eps, skip=False):
     _ready(x)
     _require_gpu(x)
-    return _RowNorm.apply(x, weight, bias, scale, shift, kind, eps)
+    return _RowNorm.apply(x, weight, bias, scale, shift, kind, eps, skip)
+
+
+def layer_norm_skip(x: torch.Tensor, weight, bias, eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """(LayerNorm(x), x): use the second output as the residual input of the branch's last layer
+    (`lora_linear(..., residual=x)` or `x + branch`); the backward then adds the residual gradient inside the
+    norm-backward kernel."""
+    return _norm(x, weight, bias, None, None, KIND_LAYER, eps, skip=True)
 
 
 def layer_norm(x: torch.Tensor, weight, bias, eps: float) -> torch.Tensor:
@@ -505,15 +520,16 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
     return x2
 
 
-def _lora_fwd_(x2: torch.Tensor, y2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, s: float):
-    """y2 += s (x2 Aᵀ) Bᵀ in place; returns (t = x2 Aᵀ, Bᵀ) for backward."""
+def _lora_fwd_(x2: torch.Tensor, y2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, s: float, residual: torch.Tensor | None = None):
+    """y2 += s (x2 Aᵀ) Bᵀ (+ residual) in place; returns (t = x2 Aᵀ, Bᵀ) for backward."""
     M, K = x2.shape
     N, r = B.shape
     t = torch.empty((M, r), dtype=torch.bfloat16, device=x2.device)
     Bt = torch.empty((r, N), dtype=torch.bfloat16, device=x2.device)
     with _Timed("lora_fwd", 2.0 * M * K + 4.0 * M * N):
-        st = _C.lib().vft_lora_fwd(_ptr(x2), _ptr(y2), _ptr(A), _ptr(B), _ptr(t), _ptr(Bt), M, K, N, r,
-                                   x2.stride(0), y2.stride(0), float(s), _stream())
+        st = _C.lib().vft_lora_fwd(_ptr(x2), _ptr(y2), _ptr(A), _ptr(B), _ptr(t), _ptr(Bt), _ptr(residual), M, K, N, r,
+                                   x2.stride(0), y2.stride(0), residual.stride(0) if residual is not None else 0,
+                                   float(s), _stream())
     _C.check(st, "vft_lora_fwd")
     return t, Bt
 
@@ -549,13 +565,19 @@ class _LoRALinear(torch.autograd.Function):
     above, applied in place on the GEMM outputs."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, B, s, qstate):
+    def forward(ctx, x, weight, bias, A, B, s, qstate, residual=None):
         x2 = _rows(x)
         A, B = A.contiguous(), B.contiguous()
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(-1, residual.shape[-1])
+            if res2.stride(-1) != 1 or res2.stride(0) % 8 != 0 or res2.dtype != torch.bfloat16:
+                res2 = res2.to(torch.bfloat16).contiguous()
         with torch.cuda.device(x.device):
             y2 = F.linear(x2, weight, bias) if qstate is None else _nf4_gemm(x2, qstate, bias, False)
-            t, Bt = _lora_fwd_(x2, y2, A, B, s)
+            t, Bt = _lora_fwd_(x2, y2, A, B, s, res2)
         ctx.save_for_backward(x2, t, Bt, weight, A, B)
+        ctx.res_shape = residual.shape if residual is not None else None
         ctx.s = s
         ctx.qstate = qstate
         ctx.xshape = x.shape
@@ -577,7 +599,8 @@ class _LoRALinear(torch.autograd.Function):
                 u = _lora_bwd_dx_(dy2, scratch, Bt, A, s)
             if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
                 dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B, s)
-        return dx, None, None, dA, dB, None, None
+        dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[7] else None
+        return dx, None, None, dA, dB, None, None, dres
 
 
 class _LoRABranch(torch.autograd.Function):
@@ -611,8 +634,9 @@ class _LoRABranch(torch.autograd.Function):
         return dx, dy, dA, dB, None
 
 
-def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.Tensor, scale: float) -> torch.Tensor:
-    """base(x) + scale * (x @ lora_down^T) @ lora_up^T with the rank-sized work in fused HIP kernels.
+def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.Tensor, scale: float,
+                residual: torch.Tensor | None = None) -> torch.Tensor:
+    """base(x) + scale * (x @ lora_down^T) @ lora_up^T (+ residual) with the rank-sized work in fused HIP kernels.
 
     `base` is the wrapped layer: a plain ``nn.Linear`` takes the fully fused path (dx is produced in
     one buffer); anything else (NF4 linear, ...) gets the in-place low-rank branch on its output."""
@@ -621,13 +645,14 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
     if lora_down.shape[0] > 16:
         raise ValueError(f"LoRA rank {lora_down.shape[0]} > 16 is not supported by the MI355X kernels")
     if type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16:
-        return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None)
+        return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None, residual)
     if hasattr(base, "quant_state"):  # NF4Linear: dequant-fused GEMM for the base products
-        return _LoRALinear.apply(x, None, base.bias, lora_down, lora_up, float(scale), base.quant_state())
+        return _LoRALinear.apply(x, None, base.bias, lora_down, lora_up, float(scale), base.quant_state(), residual)
     y = base(x)
     if not y.is_contiguous():
         y = y.contiguous()
-    return _LoRABranch.apply(x, y, lora_down, lora_up, float(scale))
+    y = _LoRABranch.apply(x, y, lora_down, lora_up, float(scale))
+    return y if residual is None else residual + y
 
 
 # =============================================================================================

@@ -13,6 +13,7 @@ cast points through ``accelerator.autocast()``).
 """
 from __future__ import annotations
 
+import inspect
 from typing import Literal, NamedTuple
 
 import torch
@@ -22,6 +23,7 @@ import torch.utils.checkpoint as checkpoint
 
 from ... import kernels
 from ...modules.attention import AttentionImplementation, scaled_dot_product_attention
+from ...modules.peft.lora import LoRALinear
 from ...modules.timestep.embedding import get_timestep_embedding
 from ...utils.tensor import module_dtype
 from .config import DOWN_BLOCK_NAME, MID_BLOCK_NAME, UP_BLOCK_NAME, DenoiserConfig
@@ -36,6 +38,15 @@ def _split_heads(t: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
     # (B, S, H*D) -> (B, H, S, D) as a strided view; the attention kernel reads it in place
     b, s, _ = t.shape
     return t.view(b, s, heads, head_dim).permute(0, 2, 1, 3)
+
+
+def _proj_residual(layer: nn.Module, h: torch.Tensor, residual: torch.Tensor | None) -> torch.Tensor:
+    """residual + layer(h); a LoRA-wrapped projection folds the add into its own kernel pass."""
+    if residual is None:
+        return layer(h)
+    if isinstance(layer, LoRALinear):
+        return layer(h, residual=residual)
+    return residual + layer(h)
 
 
 def _merge_heads(t: torch.Tensor) -> torch.Tensor:
@@ -56,12 +67,12 @@ class SelfAttention(nn.Module):
         self.to_v = nn.Linear(self.inner_dim, self.inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(self.inner_dim, self.inner_dim), nn.Dropout(dropout))
 
-    def forward(self, hidden_states: torch.Tensor, mask: torch.Tensor | None = None):
+    def forward(self, hidden_states: torch.Tensor, mask: torch.Tensor | None = None, residual: torch.Tensor | None = None):
         q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
         k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)
         v = _split_heads(self.to_v(hidden_states), self.num_heads, self.head_dim)
         attn = scaled_dot_product_attention(q, k, v, mask=mask, backend=self.attn_implementation)
-        return self.to_out(_merge_heads(attn))
+        return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
 
 class CrossAttention(nn.Module):
@@ -81,12 +92,12 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(self.inner_dim, query_dim), nn.Dropout(dropout))
 
     def forward(self, query: torch.Tensor, context: torch.Tensor, mask: torch.Tensor | None = None,
-                time_embedding: torch.Tensor | None = None, *args, **kwargs) -> torch.Tensor:
+                time_embedding: torch.Tensor | None = None, *args, residual: torch.Tensor | None = None, **kwargs) -> torch.Tensor:
         q = _split_heads(self.to_q(query), self.num_heads, self.head_dim)
         k = _split_heads(self.to_k(context), self.num_heads, self.head_dim)
         v = _split_heads(self.to_v(context), self.num_heads, self.head_dim)
         attn = scaled_dot_product_attention(q, k, v, mask=mask, backend=self.attn_implementation)
-        return self.to_out(_merge_heads(attn))
+        return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
 
 class GeGLU(nn.Module):
@@ -105,8 +116,8 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GeGLU(hidden_dim, self.intermediate_dim), nn.Dropout(dropout),
                                  nn.Linear(self.intermediate_dim, hidden_dim, bias=True))
 
-    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        return self.net(hidden_states)
+    def forward(self, hidden_states: torch.Tensor, residual: torch.Tensor | None = None) -> torch.Tensor:
+        return _proj_residual(self.net[2], self.net[1](self.net[0](hidden_states)), residual)
 
 
 class _LN(nn.LayerNorm):
@@ -114,6 +125,11 @@ class _LN(nn.LayerNorm):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return kernels.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def with_skip(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """(norm(x), x): route the second output into the branch's residual so the backward adds the skip
+        gradient inside the norm-backward kernel."""
+        return kernels.layer_norm_skip(x, self.weight, self.bias, self.eps)
 
 
 class TransformerBlock(nn.Module):
@@ -136,13 +152,23 @@ class TransformerBlock(nn.Module):
         self.norm1 = _LN(hidden_dim)
         self.norm2 = _LN(hidden_dim)
         self.norm3 = _LN(hidden_dim)
+        # substituted attention classes (self_attention_class / cross_attention_class hooks) may not know `residual`
+        self._res1 = "residual" in inspect.signature(self.attn1.forward).parameters
+        self._res2 = "residual" in inspect.signature(self.attn2.forward).parameters
 
     def forward(self, hidden_states: torch.Tensor, context: torch.Tensor, time_embedding: torch.Tensor,
                 cross_attention_kwargs: dict | None = None, *args, **kwargs) -> torch.Tensor:
+        # pre-LN residual x3 (reference :273-284); each skip add rides in the branch's last projection (forward)
+        # and in the norm's backward kernel (backward) instead of separate elementwise passes
         x = hidden_states
-        x = x + self.attn1(self.norm1(x))
-        x = x + self.attn2(self.norm2(x), context=context, time_embedding=time_embedding, **(cross_attention_kwargs or {}))
-        x = x + self.ff(self.norm3(x))
+        n, x = self.norm1.with_skip(x)
+        x = self.attn1(n, residual=x) if self._res1 else x + self.attn1(n)
+        n, x = self.norm2.with_skip(x)
+        ca = cross_attention_kwargs or {}
+        x = (self.attn2(n, context=context, time_embedding=time_embedding, residual=x, **ca) if self._res2
+             else x + self.attn2(n, context=context, time_embedding=time_embedding, **ca))
+        n, x = self.norm3.with_skip(x)
+        x = self.ff(n, residual=x)
         return x
 
 

@@ -67,16 +67,20 @@ class LoRALinear(PeftLayer):
         if self.lora_up.bias is not None:
             nn.init.zeros_(self.lora_up.bias)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None) -> torch.Tensor:
+        """`residual` (MI355X extension, optional): the enclosing block's skip connection, added in the same
+        kernel pass as the low-rank update: returns residual + layer(x)."""
         if not self.enabled:
-            return self.linear(x)
+            y = self.linear(x)
+            return y if residual is None else residual + y
         drop = self.dropout(x)
         if drop is x and self.lora_up.bias is None:
-            return kernels.lora_linear(x, self.linear, self.lora_down.weight, self.lora_up.weight, self._scale())
+            return kernels.lora_linear(x, self.linear, self.lora_down.weight, self.lora_up.weight, self._scale(), residual)
         # dropout / adapter-bias variants are not on the benchmarked path: unfused but same math
         base = self.linear(x)
         lo = self.lora_up(self.lora_down(drop))
-        return base + lo * (self.alpha / self.rank)
+        y = base + lo * (self.alpha / self.rank)
+        return y if residual is None else residual + y
 
     def _scale(self) -> float:
         # alpha is a frozen 0-d parameter; cache its host value so the hot loop never syncs
