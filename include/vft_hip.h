@@ -89,6 +89,10 @@ int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
 int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora_up, void* t_out,
                  void* up_t_out, const void* residual, int M, int K, int N, int r, int64_t ldx,
                  int64_t ldy, int64_t ldres, float scale, void* stream);
+/* t[M][r] = x . lora_down^T only: the adapter's low-rank activations, for consumers that apply the update
+ * themselves (vft_geglu_lora_*, the rank extension of vft_linear_fwd / vft_linear_nf4). */
+int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
+                  void* stream);
 int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
                     int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream);
 size_t vft_lora_wgrad_workspace(int M, int K, int N, int r);
@@ -155,6 +159,14 @@ int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float* stats, co
  */
 int vft_geglu_fwd(const void* proj, void* out, int64_t M, int F, void* stream);
 int vft_geglu_bwd(const void* proj, const void* dy, void* dproj, int64_t M, int F, void* stream);
+/* GEGLU that applies the producing projection's LoRA update on the fly (r <= 8):
+ *   out = geglu(bf16(proj + scale * t . lora_up^T));  _bwd recomputes it and writes dproj[M][2F].
+ * Saves the read-modify-write pass of the adapter over the (M, 8C) projection (peft/lora.py:92-104 followed by
+ * sdxl/denoiser.py:183-186). */
+int vft_geglu_lora_fwd(const void* proj, const void* t, const void* lora_up, void* out, int64_t M, int F, int r,
+                       float scale, void* stream);
+int vft_geglu_lora_bwd(const void* proj, const void* t, const void* lora_up, const void* dy, void* dproj,
+                       int64_t M, int F, int r, float scale, void* stream);
 int vft_swiglu_fwd(const void* a, const void* b, void* out, int64_t n, void* stream);
 int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void* db, int64_t n, void* stream);
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,

@@ -147,3 +147,38 @@ def test_lora_linear_fused_residual_and_norm_skip(gpu, M, K, N, r):
     assert rel_err(yg.cpu(), yr) < 8e-3, rel_err(yg.cpu(), yr)
     assert rel_err(xg.grad.cpu(), xr.grad) < 8e-3, rel_err(xg.grad.cpu(), xr.grad)
     assert rel_err(Ag.grad.cpu(), Ar.grad) < 1.5e-2 and rel_err(Bg.grad.cpu(), Br.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,C,r", [(1000, 640, 4), (333, 1280, 8), (77, 64, 4)])
+def test_lora_linear_geglu_fused(gpu, M, C, r):
+    """geglu(LoRALinear(x)) with the adapter applied inside the GEGLU kernel (vft_lora_down + vft_geglu_lora_*)
+    vs the fp32 composition: output, input gradient and both adapter gradients."""
+    import torch.nn.functional as F
+
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(5)
+    bf = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16)  # noqa: E731
+    Fh = 4 * C
+    x, W, b = bf(M, C), bf(2 * Fh, C, sc=C**-0.5), bf(2 * Fh, sc=0.1)
+    A, B = bf(r, C, sc=C**-0.5), bf(2 * Fh, r, sc=0.3)
+    gy = bf(M, Fh)
+    s = 0.25
+    xr, Ar, Br = x.float().requires_grad_(True), A.float().requires_grad_(True), B.float().requires_grad_(True)
+    proj = xr @ W.float().t() + b.float() + s * (xr @ Ar.t()) @ Br.t()
+    a, gate = proj.chunk(2, dim=-1)
+    yr = a * F.gelu(gate)
+    yr.backward(gy.float())
+
+    lin = torch.nn.Linear(C, 2 * Fh).to(gpu, torch.bfloat16).requires_grad_(False)
+    with torch.no_grad():
+        lin.weight.copy_(W), lin.bias.copy_(b)
+    xg, Ag, Bg = x.to(gpu).requires_grad_(True), A.to(gpu).requires_grad_(True), B.to(gpu).requires_grad_(True)
+    assert kernels.lora_geglu_eligible(xg, lin, Ag)
+    yg = kernels.lora_linear_geglu(xg, lin, Ag, Bg, s)
+    yg.backward(gy.to(gpu))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu(), yr) < 8e-3, rel_err(yg.cpu(), yr)
+    assert rel_err(xg.grad.cpu(), xr.grad) < 8e-3, rel_err(xg.grad.cpu(), xr.grad)
+    assert rel_err(Ag.grad.cpu(), Ar.grad) < 1.5e-2, rel_err(Ag.grad.cpu(), Ar.grad)
+    assert rel_err(Bg.grad.cpu(), Br.grad) < 1.5e-2, rel_err(Bg.grad.cpu(), Br.grad)

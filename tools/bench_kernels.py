@@ -84,6 +84,28 @@ def norm():
         print(f"geglu M={M} F={F}: {tf*1e6:7.1f} us {6*M*F/tf/1e9:7.0f} GB/s")
 
 
+def geglu_lora():
+    print("== GEGLU: plain (on a materialised LoRA projection: lora_fwd pass + geglu) vs LoRA applied inside GEGLU ==")
+    for M, C in [(65536, 640), (16384, 1280)]:
+        Fh = 4 * C
+        lin = torch.nn.Linear(C, 2 * Fh).to(dev, torch.bfloat16).requires_grad_(False)
+        x = bf(M, C)
+        A, B = bf(4, C).requires_grad_(True), bf(2 * Fh, 4).requires_grad_(True)
+        proj = lin(x)
+        t = kernels.lora_down(x, A.detach())
+        gy = bf(M, Fh)
+        pr = proj.clone().requires_grad_(True)
+        tf = timeit(lambda: kernels.geglu(pr))
+        tff = timeit(lambda: kernels._GeGLULoRA.apply(pr, t, B.detach(), 0.25))
+        o1 = kernels.geglu(pr)
+        tb = timeit(lambda: torch.autograd.grad(o1, pr, gy, retain_graph=True))
+        o2 = kernels._GeGLULoRA.apply(pr, t, B.detach(), 0.25)
+        tbf = timeit(lambda: torch.autograd.grad(o2, pr, gy, retain_graph=True))
+        tl = timeit(lambda: kernels._lora_fwd_(x, proj, A.detach(), B.detach(), 0.25))
+        print(f"M={M} C={C}: geglu fwd {tf*1e6:6.1f} us, fused fwd {tff*1e6:6.1f} us | bwd {tb*1e6:6.1f} us, fused bwd {tbf*1e6:6.1f} us"
+              f" | lora_fwd pass it replaces {tl*1e6:6.1f} us", flush=True)
+
+
 def gemm():
     import torch.nn.functional as F
 
@@ -139,6 +161,8 @@ if __name__ == "__main__":
         attn()
     if which in ("norm", "all"):
         norm()
+    if which in ("geglu", "all"):
+        geglu_lora()
     if which in ("gemm", "all"):
         gemm()
     if which in ("linear", "all"):

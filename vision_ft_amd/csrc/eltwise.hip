@@ -56,6 +56,110 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     }
 }
 
+// GEGLU with the producing projection's LoRA update applied on the fly:
+//     p_eff[m][n] = bf16(proj[m][n] + s * Σ_j t[m][j] * B[n][j]),   out = p_eff[:, :F] * gelu(p_eff[:, F:])
+// so the adapter of the (C -> 8C) GEGLU projection never costs a read-modify-write pass over the widest
+// activation of the block (the reference materialises it: peft/lora.py:92-104 then sdxl/denoiser.py:183-186).
+// One workgroup = 16 token rows; a thread owns 8 value + 8 gate columns with their 2x8xr coefficients in
+// registers and walks the rows (the lora_rows_kernel phase-2 map).  BWD recomputes p_eff and writes dproj.
+template <int RC, bool BWD>
+__global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restrict__ proj, const bf16_t* __restrict__ t,
+                                                         const bf16_t* __restrict__ Bw, const bf16_t* __restrict__ dy,
+                                                         bf16_t* __restrict__ out, int M, int F, int r, float s) {
+    __shared__ float ts[16][RC + 1];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 16;
+    const int nrows = min(16, M - m0);
+    if (tid < 16 * RC) {
+        const int row = tid / RC, j = tid % RC;
+        ts[row][j] = (row < nrows && j < r) ? s * (float)t[(int64_t)(m0 + row) * r + j] : 0.f;
+    }
+    __syncthreads();
+    const int G = F >> 3;
+    const int npass = (G + 127) >> 7;
+    const int cw = (G + npass - 1) / npass;
+    const int rp = 256 / cw;
+    const int lr = tid / cw, lc = tid - lr * cw;
+    if (lr >= rp) return;
+    for (int c0 = 0; c0 < G; c0 += cw) {
+        if (c0 + lc >= G) break;
+        const int f0 = (c0 + lc) * 8;
+        float wa[8][RC], wg[8][RC];
+        if (r == RC) {  // the 8 columns' coefficients are one contiguous run of 8*r elements: RC 16-byte loads
+            bf16x8 va[RC], vg[RC];
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                va[q] = *reinterpret_cast<const bf16x8*>(Bw + (int64_t)f0 * RC + 8 * q);
+                vg[q] = *reinterpret_cast<const bf16x8*>(Bw + (int64_t)(F + f0) * RC + 8 * q);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < RC; ++j) {
+                    wa[c][j] = (float)va[(c * RC + j) >> 3][(c * RC + j) & 7];
+                    wg[c][j] = (float)vg[(c * RC + j) >> 3][(c * RC + j) & 7];
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < RC; ++j) {
+                    wa[c][j] = j < r ? (float)Bw[(int64_t)(f0 + c) * r + j] : 0.f;
+                    wg[c][j] = j < r ? (float)Bw[(int64_t)(F + f0 + c) * r + j] : 0.f;
+                }
+        }
+        // rows in batches of NB: every load of a batch is in flight before the first FMA
+        constexpr int NB = BWD ? 2 : 4;
+        for (int i0 = lr; i0 < nrows; i0 += NB * rp) {
+            float a[NB][8], g[NB][8], d[BWD ? NB : 1][8];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int i = i0 + b * rp;
+                if (i < nrows) {
+                    const int64_t m = m0 + i;
+                    ld8(proj + m * 2 * F + f0, a[b]);
+                    ld8(proj + m * 2 * F + F + f0, g[b]);
+                    if (BWD) ld8(dy + m * F + f0, d[b]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int i = i0 + b * rp;
+                if (i >= nrows) break;
+                const int64_t m = m0 + i;
+                float tv[RC];
+#pragma unroll
+                for (int j = 0; j < RC; ++j) tv[j] = ts[i][j];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) {
+                        a[b][c] = fmaf(tv[j], wa[c][j], a[b][c]);
+                        g[b][c] = fmaf(tv[j], wg[c][j], g[b][c]);
+                    }
+                    a[b][c] = (float)(bf16_t)a[b][c];  // the projection output is a bf16 tensor in the reference
+                    g[b][c] = (float)(bf16_t)g[b][c];
+                }
+                if (!BWD) {
+                    float o[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = a[b][c] * gelu_f(g[b][c]);
+                    st8(out + m * F + f0, o);
+                } else {
+                    float da[8], dg[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        da[c] = d[b][c] * gelu_f(g[b][c]);
+                        dg[c] = d[b][c] * a[b][c] * dgelu_f(g[b][c]);
+                    }
+                    st8(out + m * 2 * F + f0, da);
+                    st8(out + m * 2 * F + F + f0, dg);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                          bf16_t* __restrict__ out, int64_t nvec) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (int64_t)gridDim.x * 256) {
@@ -155,5 +259,45 @@ extern "C" int vft_gate_residual(const void* residual, const void* gate, const v
                        (const bf16_t*)residual, (const bf16_t*)gate, (const bf16_t*)y, (bf16_t*)out, rows, C,
                        rows_per_batch, use_tanh);
     VFT_CHECK_LAUNCH("vft_gate_residual");
+    return 0;
+}
+
+static int geglu_lora_args(const char* name, const void* proj, const void* t, const void* lora_up, const void* out, int64_t M,
+                           int F, int r) {
+    VFT_CHECK_ARG(proj && t && lora_up && out, "%s: null pointer", name);
+    VFT_CHECK_ARG(M > 0 && M < (1LL << 31) && F > 0 && F % 8 == 0 && r > 0 && r <= 8, "%s: need 0 < M < 2^31, F %% 8 == 0, 0 < r <= 8 (M=%lld F=%d r=%d)",
+                  name, (long long)M, F, r);
+    VFT_CHECK_ARG((((uintptr_t)proj | (uintptr_t)out) & 15) == 0, "%s: activations must be 16-byte aligned", name);
+    return 0;
+}
+
+// out[M][F] = geglu(proj[M][2F] + scale * t[M][r] . lora_up[2F][r]^T)
+extern "C" int vft_geglu_lora_fwd(const void* proj, const void* t, const void* lora_up, void* out, int64_t M, int F, int r,
+                                  float scale, void* stream) {
+    if (geglu_lora_args("vft_geglu_lora_fwd", proj, t, lora_up, out, M, F, r)) return 1;
+    const dim3 grid((unsigned)((M + 15) / 16));
+    if (r <= 4)
+        hipLaunchKernelGGL((geglu_lora_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
+                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale);
+    else
+        hipLaunchKernelGGL((geglu_lora_kernel<8, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
+                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale);
+    VFT_CHECK_LAUNCH("vft_geglu_lora_fwd");
+    return 0;
+}
+
+// dproj[M][2F] from dy[M][F], recomputing the adapted projection
+extern "C" int vft_geglu_lora_bwd(const void* proj, const void* t, const void* lora_up, const void* dy, void* dproj, int64_t M,
+                                  int F, int r, float scale, void* stream) {
+    if (geglu_lora_args("vft_geglu_lora_bwd", proj, t, lora_up, dproj, M, F, r)) return 1;
+    VFT_CHECK_ARG(dy != nullptr && ((uintptr_t)dy & 15) == 0, "vft_geglu_lora_bwd: bad dy pointer");
+    const dim3 grid((unsigned)((M + 15) / 16));
+    if (r <= 4)
+        hipLaunchKernelGGL((geglu_lora_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
+                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale);
+    else
+        hipLaunchKernelGGL((geglu_lora_kernel<8, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
+                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale);
+    VFT_CHECK_LAUNCH("vft_geglu_lora_bwd");
     return 0;
 }

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
         if (p_out != nullptr && j < r && m0 + row < M) p_out[(int64_t)(m0 + row) * r + j] = (bf16_t)v;
     }
     __syncthreads();
+    if (N == 0) return;  // vft_lora_down: only the rank-r activations are wanted
     // ---- phase 2 ----
     // Thread map: the N/8 column groups are cut into passes of cw <= 128 groups and the 256 threads
     // cover cw groups x rp rows at once, so narrow layers (N = 640: 80 groups) still use ~all lanes.
@@ -336,6 +337,18 @@ extern "C" int vft_lora_fwd(const void* x, void* y, const void* lora_down, const
     VFT_CHECK_ARG(residual == nullptr || (ldres % 8 == 0 && ((uintptr_t)residual & 15) == 0), "vft_lora_fwd: bad residual pointer / stride");
     launch_rows<true>(x, y, lora_down, lora_up, t_out, up_t_out, residual, ldres, M, K, N, r, ldx, ldy, scale, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_lora_fwd");
+    return 0;
+}
+
+// t[M][r] = x[M][K] . lora_down[r][K]^T only (the low-rank activations; the update itself is applied by the consumer:
+// vft_geglu_lora_*, or the rank extension of vft_linear_fwd / vft_linear_nf4)
+extern "C" int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
+                             void* stream) {
+    if (chk(x && lora_down && t_out, "vft_lora_down: null pointer")) return 1;
+    VFT_CHECK_ARG(M > 0 && K > 0 && r > 0 && r <= 16 && K % 8 == 0 && ldx % 8 == 0, "vft_lora_down: need M,K>0, 0<r<=16, K and ldx multiples of 8");
+    VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)lora_down) & 15) == 0, "vft_lora_down: operands must be 16-byte aligned");
+    launch_rows<true>(x, nullptr, lora_down, nullptr, t_out, nullptr, nullptr, 0, M, K, 0, r, ldx, 0, 1.f, (hipStream_t)stream);
+    VFT_CHECK_LAUNCH("vft_lora_down");
     return 0;
 }
 

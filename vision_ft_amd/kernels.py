@@ -603,6 +603,103 @@ class _LoRALinear(torch.autograd.Function):
         return dx, None, None, dA, dB, None, None, dres
 
 
+def lora_down(x2: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
+    """t = x2 @ A^T (M, r): the adapter's low-rank activations (vft_lora_down); no autograd."""
+    M, K = x2.shape
+    r = A.shape[0]
+    t = torch.empty((M, r), dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device), _Timed("lora_down", 2.0 * M * K):
+        st = _C.lib().vft_lora_down(_ptr(x2), _ptr(A), _ptr(t), M, K, r, x2.stride(0), _stream())
+    _C.check(st, "vft_lora_down")
+    return t
+
+
+class _LoRALinearDeferred(torch.autograd.Function):
+    """(x Wᵀ + b, t = x Aᵀ): the base projection and the adapter's low-rank activations; the update
+    s·t·Bᵀ is applied by the consumer (`geglu_lora`).  Since d(loss)/d(base output) = d(loss)/d(adapted output),
+    the backward is that of `_LoRALinear` with the consumer's input gradient as dy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, A, B, s):
+        x2 = _rows(x)
+        A = A.contiguous()
+        with torch.cuda.device(x.device):
+            y2 = F.linear(x2, weight, bias)
+            t = lora_down(x2, A)
+        ctx.save_for_backward(x2, t, weight, A, B)
+        ctx.s = s
+        ctx.xshape = x.shape
+        ctx.mark_non_differentiable(t)
+        return y2.view(*x.shape[:-1], weight.shape[0]), t
+
+    @staticmethod
+    def backward(ctx, dy, _dt):
+        x2, t, weight, A, B = ctx.saved_tensors
+        s = ctx.s
+        dy2 = _rows(dy)
+        Bt = B.t().contiguous()
+        dx = dA = dB = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[0]:
+                dx2 = dy2 @ weight
+                u = _lora_bwd_dx_(dy2, dx2, Bt, A, s)
+                dx = dx2.view(ctx.xshape)
+            else:
+                scratch = torch.empty((dy2.shape[0], A.shape[1]), dtype=dy.dtype, device=dy.device)
+                u = _lora_bwd_dx_(dy2, scratch, Bt, A, s)
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B.contiguous(), s)
+        return dx, None, None, dA, dB, None
+
+
+class _GeGLULoRA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj, t, B, s):
+        F2 = proj.shape[-1]
+        p2 = _rows(proj)
+        if p2.stride(0) != F2:
+            p2 = p2.contiguous()
+        M, Fh = p2.shape[0], F2 // 2
+        B = B.contiguous()
+        out = torch.empty((M, Fh), dtype=torch.bfloat16, device=proj.device)
+        with torch.cuda.device(proj.device), _Timed("geglu_fwd", 6.0 * M * Fh):
+            st = _C.lib().vft_geglu_lora_fwd(_ptr(p2), _ptr(t), _ptr(B), _ptr(out), M, Fh, B.shape[1], float(s), _stream())
+        _C.check(st, "vft_geglu_lora_fwd")
+        ctx.save_for_backward(p2, t, B)
+        ctx.s = s
+        ctx.pshape = proj.shape
+        return out.view(*proj.shape[:-1], Fh)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p2, t, B = ctx.saved_tensors
+        M, F2 = p2.shape
+        Fh = F2 // 2
+        dy2 = dy.reshape(M, Fh)
+        if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
+            dy2 = dy2.to(torch.bfloat16).contiguous()
+        dproj = torch.empty((M, F2), dtype=torch.bfloat16, device=dy.device)
+        with torch.cuda.device(dy.device), _Timed("geglu_bwd", 10.0 * M * Fh):
+            st = _C.lib().vft_geglu_lora_bwd(_ptr(p2), _ptr(t), _ptr(B), _ptr(dy2), _ptr(dproj), M, Fh, B.shape[1],
+                                             float(ctx.s), _stream())
+        _C.check(st, "vft_geglu_lora_bwd")
+        return dproj.view(ctx.pshape), None, None, None
+
+
+def lora_geglu_eligible(x: torch.Tensor, base, lora_down_w: torch.Tensor) -> bool:
+    return (type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16 and x.is_cuda
+            and lora_down_w.shape[0] <= 8 and base.out_features % 16 == 0)
+
+
+def lora_linear_geglu(x: torch.Tensor, base, lora_down_w: torch.Tensor, lora_up_w: torch.Tensor, scale: float) -> torch.Tensor:
+    """geglu(base(x) + scale * (x @ lora_down^T) @ lora_up^T) without materialising the adapted projection: the
+    base GEMM, the rank-r activations, and a GEGLU kernel that applies the update on the fly."""
+    _ready(x, lora_down_w, lora_up_w)
+    _require_gpu(x, lora_down_w, lora_up_w)
+    proj, t = _LoRALinearDeferred.apply(x, base.weight, base.bias, lora_down_w, lora_up_w, float(scale))
+    return _GeGLULoRA.apply(proj, t, lora_up_w.detach(), float(scale))
+
+
 class _LoRABranch(torch.autograd.Function):
     """y += s·(x Aᵀ) Bᵀ in place on the output of an arbitrary base layer (e.g. the NF4 linear)."""
 

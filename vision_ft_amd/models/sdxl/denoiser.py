@@ -106,7 +106,12 @@ class GeGLU(nn.Module):
         self.proj = nn.Linear(in_dim, out_dim * 2)
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        return kernels.geglu(self.proj(hidden_states))
+        p = self.proj
+        if (isinstance(p, LoRALinear) and p.enabled and not p.training_dropout_active()
+                and kernels.lora_geglu_eligible(hidden_states, p.linear, p.lora_down.weight)):
+            # the adapter's update is applied inside the GEGLU kernel: no extra pass over the (M, 8C) projection
+            return kernels.lora_linear_geglu(hidden_states, p.linear, p.lora_down.weight, p.lora_up.weight, p._scale())
+        return kernels.geglu(p(hidden_states))
 
 
 class FeedForward(nn.Module):

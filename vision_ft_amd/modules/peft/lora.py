@@ -82,6 +82,12 @@ class LoRALinear(PeftLayer):
         y = base + lo * (self.alpha / self.rank)
         return y if residual is None else residual + y
 
+    def training_dropout_active(self) -> bool:
+        """True when the adapter input goes through an active dropout (or the up-projection has a bias): the
+        fused kernels do not cover those variants."""
+        d = self.dropout
+        return (isinstance(d, nn.Dropout) and d.p > 0 and self.training) or self.lora_up.bias is not None
+
     def _scale(self) -> float:
         # alpha is a frozen 0-d parameter; cache its host value so the hot loop never syncs
         s = getattr(self, "_scale_cache", None)
