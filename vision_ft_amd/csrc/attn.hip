@@ -90,10 +90,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
 template <int D, int ROWS>
 struct TileStage {
     static constexpr int CPR = D / 8;               // 16-byte chunks per row
-    static constexpr int NCH = ROWS * CPR / 256;    // chunks per thread
-    static constexpr bool REG = (256 % CPR) == 0;   // chunk i of a thread = chunk 0 shifted by i*(256/CPR) rows
+    static constexpr int TOTAL = ROWS * CPR;
+    static constexpr int NCH = (TOTAL + 255) / 256;  // chunks per thread (the last pass may be partial)
+    static constexpr bool FULL = TOTAL % 256 == 0;
+    static constexpr bool REG = FULL && (256 % CPR) == 0;  // chunk i of a thread = chunk 0 shifted by i*(256/CPR) rows
     static constexpr int NP = REG ? 1 : NCH;
-    static_assert(ROWS * CPR % 256 == 0, "tile must split evenly over 256 threads");
     u32x4 r[NCH];
     const bf16_t* gp[NP];
     int lrow[NP];
@@ -126,6 +127,7 @@ struct TileStage {
                 src = gp[i % NP] + toff;
                 row = lrow[i % NP];
             }
+            if (!FULL && i * 256 + (int)threadIdx.x >= TOTAL) continue;  // partial last pass
             if (row0 + row < row_limit) {
                 r[i] = *reinterpret_cast<const u32x4*>(src);
             } else {
@@ -137,6 +139,7 @@ struct TileStage {
         constexpr int LD = D + 8;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
+            if (!FULL && i * 256 + (int)threadIdx.x >= TOTAL) continue;
             const int off = REG ? loff[0] + i * (256 / CPR) * LD : loff[i % NP];
             *reinterpret_cast<u32x4*>(lds + off) = r[i];
         }
