@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 // loops over the query heads that share this kv head
 // =============================================================================================
 template <int D, int BQ>
-__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnParams p) {
     constexpr int LD = D + 8, KS = D / 16, DT = D / 32, QT = BQ / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two buffers of [Q tile | dO tile | lse | delta]: the next tile is written while this one is read,
@@ -609,7 +609,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
             if (it + 2 < it1) prefetch(it + 2);
         }
 
-        bf16x8 Pf[2 * QT], dSf[2 * QT];
+        // per 32-query sub-tile: S, dP -> P, dS (packed bf16) -> its share of dV / dK right away, so only one
+        // sub-tile's fragments are live at a time (register pressure decides the waves per SIMD here)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             f32x16 S, dP;
@@ -637,21 +638,23 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
                     dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
                 }
             }
-            Pf[qt * 2] = pack8(S, 0);
-            Pf[qt * 2 + 1] = pack8(S, 1);
-            dSf[qt * 2] = pack8(dP, 0);
-            dSf[qt * 2 + 1] = pack8(dP, 1);
+            bf16x8 Pf[2], dSf[2];
+            Pf[0] = pack8(S, 0);
+            Pf[1] = pack8(S, 1);
+            dSf[0] = pack8(dP, 0);
+            dSf[1] = pack8(dP, 1);
+            // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int kk = 2 * qt + k2;
+                    bf16x8 a = tr_frag(dotr, LD, kk * 16, dt * 32);
+                    dV[dt] = mfma32(a, Pf[k2], dV[dt]);
+                    bf16x8 c = tr_frag(qtr, LD, kk * 16, dt * 32);
+                    dK[dt] = mfma32(c, dSf[k2], dK[dt]);
+                }
         }
-        // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int kk = 0; kk < 2 * QT; ++kk) {
-                bf16x8 a = tr_frag(dotr, LD, kk * 16, dt * 32);
-                dV[dt] = mfma32(a, Pf[kk], dV[dt]);
-                bf16x8 c = tr_frag(qtr, LD, kk * 16, dt * 32);
-                dK[dt] = mfma32(c, dSf[kk], dK[dt]);
-            }
         __syncthreads();
     }
     if (p.nsplit > 1) {
