@@ -111,6 +111,37 @@ def test_nf4_linear_forward_backward(gpu, M, out_f, in_f, dq):
     assert rel_err(xg.grad.cpu(), gy.float() @ wb) < 5e-3, rel_err(xg.grad.cpu(), gy.float() @ wb)
 
 
+@pytest.mark.parametrize("M,out_f,in_f,r,dq,res", [(520, 3840, 2304, 4, True, False), (333, 2304, 2304, 8, True, True),
+                                                   (1000, 256, 128, 16, False, True)])
+def test_qlora_linear_one_launch_per_direction(gpu, M, out_f, in_f, r, dq, res):
+    """NF4 base + LoRA (+ residual) through vft_lora_down + vft_linear_nf4 with the rank extension: output, input
+    gradient and adapter gradients vs fp32 math on the dequantised weight."""
+    from vision_ft_amd import kernels
+
+    layer, wd, b, _ = _make_layer(gpu, out_f, in_f, dq)
+    g = torch.Generator().manual_seed(9)
+    x, gy = _bf(g, M, in_f), _bf(g, M, out_f)
+    A, B = _bf(g, r, in_f, sc=in_f**-0.5), _bf(g, out_f, r, sc=0.3)
+    rs = _bf(g, M, out_f) if res else None
+    s = 0.25
+    wb = wd.to(torch.bfloat16).float()
+    xr, Ar, Br = x.float().requires_grad_(True), A.float().requires_grad_(True), B.float().requires_grad_(True)
+    yr = xr @ wb.t() + b.float() + s * (xr @ Ar.t()) @ Br.t()
+    if res:
+        yr = yr + rs.float()
+    yr.backward(gy.float())
+    xg, Ag, Bg = x.to(gpu).requires_grad_(True), A.to(gpu).requires_grad_(True), B.to(gpu).requires_grad_(True)
+    rg = rs.to(gpu).requires_grad_(True) if res else None
+    y = kernels.lora_linear(xg, layer, Ag, Bg, s, residual=rg)
+    y.backward(gy.to(gpu))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), yr) < 6e-3, rel_err(y.cpu(), yr)
+    assert rel_err(xg.grad.cpu(), xr.grad) < 6e-3, rel_err(xg.grad.cpu(), xr.grad)
+    assert rel_err(Ag.grad.cpu(), Ar.grad) < 1.2e-2 and rel_err(Bg.grad.cpu(), Br.grad) < 1.2e-2
+    if res:
+        assert torch.equal(rg.grad.cpu(), gy)
+
+
 def test_nf4_state_dict_layout_and_roundtrip(gpu):
     """Mirrors the reference's tests/test_modules_quant.py:153-193: key names, uint8 storage, reload
     self-consistency."""

@@ -614,6 +614,46 @@ def lora_down(x2: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
     return t
 
 
+class _QLoRALinear(torch.autograd.Function):
+    """NF4 base + LoRA, each direction ONE GEMM launch: the rank-r activations (t = x Aᵀ forward, u = dy B backward)
+    come from `vft_lora_down`, the update enters the NF4 GEMM's accumulators as r extra K columns (`vft_linear_nf4`
+    with ext_x / ext_w), so neither the adapter nor the 4-bit base ever costs a separate pass over y / dx
+    (reference: LoRALinear over BnbLinear4bit = bnb dequant kernel + GEMM + 3 adapter GEMMs + scale + add)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, A, B, s, qstate, residual=None):
+        x2 = _rows(x)
+        A, B = A.contiguous(), B.contiguous()
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(-1, residual.shape[-1])
+            if res2.stride(-1) != 1 or res2.stride(0) % 8 != 0 or res2.dtype != torch.bfloat16:
+                res2 = res2.to(torch.bfloat16).contiguous()
+        with torch.cuda.device(x.device):
+            t = lora_down(x2, A)
+            y2 = _nf4_gemm(x2, qstate, bias, False, ext_x=t, ext_w=(B * s).to(torch.bfloat16), residual=res2)
+        ctx.save_for_backward(x2, t, A, B)
+        ctx.s, ctx.qstate, ctx.xshape = s, qstate, x.shape
+        ctx.res_shape = residual.shape if residual is not None else None
+        return y2.view(*x.shape[:-1], B.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t, A, B = ctx.saved_tensors
+        s = ctx.s
+        dy2 = _rows(dy)
+        dx = dA = dB = None
+        with torch.cuda.device(dy.device):
+            u = lora_down(dy2, B.t().contiguous())  # (M, r) = dy . B
+            if ctx.needs_input_grad[0]:
+                dx2 = _nf4_gemm(dy2, ctx.qstate, None, True, ext_x=u, ext_w=(A.t() * s).to(torch.bfloat16).contiguous())
+                dx = dx2.view(ctx.xshape)
+            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+                dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B, s)
+        dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[6] else None
+        return dx, None, dA, dB, None, None, dres
+
+
 class _LoRALinearDeferred(torch.autograd.Function):
     """(x Wᵀ + b, t = x Aᵀ): the base projection and the adapter's low-rank activations; the update
     s·t·Bᵀ is applied by the consumer (`geglu_lora`).  Since d(loss)/d(base output) = d(loss)/d(adapted output),
@@ -744,7 +784,11 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
     if type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16:
         return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None, residual)
     if hasattr(base, "quant_state"):  # NF4Linear: dequant-fused GEMM for the base products
-        return _LoRALinear.apply(x, None, base.bias, lora_down, lora_up, float(scale), base.quant_state(), residual)
+        q = base.quant_state()
+        r = lora_down.shape[0]
+        if r in (4, 8, 16) and q.in_features % 64 == 0 and q.out_features % 64 == 0:
+            return _QLoRALinear.apply(x, base.bias, lora_down, lora_up, float(scale), q, residual)
+        return _LoRALinear.apply(x, None, base.bias, lora_down, lora_up, float(scale), q, residual)
     y = base(x)
     if not y.is_contiguous():
         y = y.contiguous()
