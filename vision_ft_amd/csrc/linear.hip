@@ -96,6 +96,22 @@ __device__ __forceinline__ void asm_load_b32(float& d, const void* p) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
 
+// MFMA 32x32x16 A-operand fragment (32 rows n x 16 k) out of a [k][n] row-major LDS tile by two transposed reads
+// (ds_read_b64_tr_b16): lane half h gets k = 8h .. 8h+7 of row n = lane & 31 — the same k order as a plain
+// ds_read_b128 of a [n][k] tile, so the activation operand needs no permutation.
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+__device__ __forceinline__ int tr_lane_off_nat(int ld, int lane) {
+    const int h = lane >> 5, i = lane & 15;
+    return (8 * h + (i >> 2)) * ld + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+}
+__device__ __forceinline__ bf16x8 tr_frag_nat(const bf16_t* lane_base, int ld, int row0, int col0) {
+    const bf16_t* a0 = lane_base + row0 * ld + col0;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a0 + 4 * ld));
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -116,7 +132,8 @@ struct Cfg {
     static constexpr int WAVES_PER_SIMD = WAVES_PER_SIMD_;
     static constexpr bool DMA_IN_M = DMA_IN_M_;
     static constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 32, FN = TN / 32;
-    static constexpr int A_STAGE = BM * KST, B_STAGE = BN * KST, STAGE = A_STAGE + B_STAGE;  // elements
+    static constexpr int WT_LD = BN + 8;  // WMODE 2: the weight tile is kept in W's own orientation, [64 k'][BN n' + pad]
+    static constexpr int A_STAGE = BM * KST, B_STAGE = WMODE_ == 2 ? KST * WT_LD : BN * KST, STAGE = A_STAGE + B_STAGE;  // elements
     static constexpr int DMA_A = BM / (8 * RPD), DMA_B = WMODE_ ? 0 : BN / (8 * RPD);
     static constexpr int QW = BN / 64;                       // NF4: packed dwords per thread per stage (8 weights each)
     static constexpr int DMA = DMA_A + (WMODE_ ? 2 : DMA_B);  // VM operations per wave per stage (NF4: codes + absmax loads)
@@ -243,12 +260,11 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = v[e];
                 *reinterpret_cast<bf16x8*>(sb + qrow * KS + ((chunk ^ ((qrow >> 1) & 7)) << 3)) = o;
-            } else {
+            } else {  // W's own orientation: row k' = qrow, columns n' = qseg*8*QW + 8w .. +7; read back transposed
+                bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int nl = qseg * 8 * QW + w * 8 + e;
-                    sb[nl * KS + (((qrow >> 3) ^ ((nl >> 1) & 7)) << 3) + (qrow & 7)] = v[e];
-                }
+                for (int e = 0; e < 8; ++e) o[e] = v[e];
+                *reinterpret_cast<bf16x8*>(sb + qrow * C::WT_LD + qseg * 8 * QW + w * 8) = o;
             }
         }
     };
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     // fragment read offsets (elements): row * KS + ((chunk ^ sw) << 3); chunk = 2 * kk + h for MFMA k-step kk
     const int sw = KS == 32 ? ((r32 >> 2) & 3) : ((r32 >> 1) & 7);
     const int xrow = (wm * C::TM + r32) * KS, wrow = A_STAGE + (wn * C::TN + r32) * KS;
+    const int wtr = tr_lane_off_nat(C::WT_LD, lane);  // WMODE 2
 
     const int nkt = p.K / KS;
     // prologue: stages 0 .. NSTAGE-2 in flight, stage 0 landed for everyone, then stagger the groups
@@ -344,8 +361,13 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
             bf16x8 fw[2][FN], fx[2][FM];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-                fw[0][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co0);
-                fw[1][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co1);
+                if (C::WMODE == 2) {
+                    fw[0][i] = tr_frag_nat(st + A_STAGE + wtr, C::WT_LD, 32 * ph, wn * C::TN + i * 32);
+                    fw[1][i] = tr_frag_nat(st + A_STAGE + wtr, C::WT_LD, 32 * ph + 16, wn * C::TN + i * 32);
+                } else {
+                    fw[0][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co0);
+                    fw[1][i] = *reinterpret_cast<const bf16x8*>(st + wrow + i * 32 * KS + co1);
+                }
             }
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
