@@ -276,16 +276,18 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
     // CONV: K index = tap * Cin + c (the channels-last weight layout); K-steps are issued in increasing order,
     // so the (tap, channel offset) of the next step is tracked incrementally
     int ctap = 0, cc0 = 0;
+    // NF4: this thread's packed codes + absmax of stage t -> registers.  Program order per stage is
+    // [staging loads][the stage's A DMAs], so `wait_q` (vmcnt(DMA_A)) retires exactly the staging loads.
+    auto issue_q = [&](int t) {
+        if (QW == 2)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qreg) : "v"(qcp + (int64_t)t * qcs) : "memory");
+        else
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qreg) : "v"(qcp + (int64_t)t * qcs) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(qam) : "v"(qap + (int64_t)t * qas) : "memory");
+    };
     auto issue = [&](int t, int slot) {
         bf16_t* st = smem + slot * STAGE;
         const int k0 = t * KS;
-        if (C::WMODE != 0) {  // before the DMAs: vmcnt(DMA_A) then retires exactly these two
-            if (QW == 2)
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(qreg) : "v"(qcp + (int64_t)t * qcs) : "memory");
-            else
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qreg) : "v"(qcp + (int64_t)t * qcs) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(qam) : "v"(qap + (int64_t)t * qas) : "memory");
-        }
         if (C::CONV) {
             const int64_t off = (int64_t)((ctap / 3 - 1) * p.cW + (ctap % 3 - 1)) * p.ldx + cc0;
 #pragma unroll
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 < nkt) {
+            if (C::WMODE != 0) issue_q(s0);
             issue(s0, s0);
             if (C::WMODE != 0) {
                 wait_q();
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
+        if (NSTAGE - 1 < nkt) issue_q(NSTAGE - 1);  // staging loads run one phase ahead of their stage's DMAs
     } else if (nkt >= NSTAGE - 1) {
         wait_vm<(NSTAGE - 2) * C::DMA>();
     } else {
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
 
     // vmcnt that retires this wave's DMAs of stage t+1 in the last phase of stage t: stages up to t+NSTAGE-1
     // (issued in R) or t+NSTAGE-2 (issued in M) are outstanding behind it
-    constexpr int INFLIGHT = C::WMODE != 0 ? (NSTAGE > 2 ? C::DMA_A : 0)  // (the staging-load wait already retired older stages)
+    constexpr int INFLIGHT = C::WMODE != 0 ? (NSTAGE > 2 ? C::DMA_A + 2 : 2)  // (the staging-load wait already retired older
+                                                                             // stages; 2 = the next stage's staging loads)
                                            : (C::DMA_IN_M ? NSTAGE - 3 : NSTAGE - 2) * C::DMA;
     constexpr int PH = KS / 32;  // phases (32-deep) per stage
     int rs = 0;            // ring slot of stage t
@@ -375,12 +380,15 @@ __global__ __launch_bounds__(NTHREADS, C::WAVES_PER_SIMD) void linear_kernel(Lin
                 fx[1][j] = *reinterpret_cast<const bf16x8*>(st + xrow + j * 32 * KS + co1);
             }
             if (ph == 0 && !C::DMA_IN_M && more) issue(t + NSTAGE - 1, ws);
-            if (C::WMODE != 0 && ph == 1 && more) {  // one phase after their issue: dequantise into the stage
+            if (C::WMODE != 0 && ph == 1 && more) {  // two phases after their issue: dequantise into the stage
                 wait_q();
                 nf4_store(ws);
+                if (t + NSTAGE < nkt) issue_q(t + NSTAGE);
             }
             if (ph == PH - 1) {
-                if (more) {
+                if (more && C::WMODE != 0 && !(t + NSTAGE < nkt)) {  // no staging loads were issued behind the DMAs
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTAGE > 2 ? C::DMA_A : 0) : "memory");
+                } else if (more) {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
