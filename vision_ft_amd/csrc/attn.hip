@@ -728,11 +728,23 @@ __host__ inline int dkdv_nsplit(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     const int BQ = D == 256 ? 32 : 64;
     const int64_t blocks = (int64_t)((Sk + 127) / 128) * B * Hkv;
     const int64_t niter = (int64_t)(Hq / Hkv) * ((Sq + BQ - 1) / BQ);
-    if (blocks >= 256) return 1;
-    int64_t ns = (512 + blocks - 1) / blocks;
-    if (ns > niter / 4) ns = niter / 4;
-    if (ns > 32) ns = 32;
-    return ns < 1 ? 1 : (int)ns;
+    const int64_t slots = 256 * (D <= 96 ? 2 : 1);  // workgroups the chip holds at once (launch bounds above)
+    if (blocks < 256) {  // too few workgroups to fill the chip
+        int64_t ns = (512 + blocks - 1) / blocks;
+        if (ns > niter / 4) ns = niter / 4;
+        if (ns > 32) ns = 32;
+        return ns < 1 ? 1 : (int)ns;
+    }
+    // enough workgroups, but a short last round can waste a large share of the chip (e.g. Lumina2: 1088 workgroups
+    // on 512 slots = 2.1 rounds): split while the quantisation loss is above 12 % and the partial sums stay cheap
+    auto eff = [&](int64_t ns) {
+        const double rounds = (double)(blocks * ns) / (double)slots;
+        return rounds / (double)((blocks * ns + slots - 1) / slots);
+    };
+    int best = 1;
+    for (int ns = 2; ns <= 4 && eff(best) < 0.88; ++ns)
+        if (niter / ns >= 16 && eff(ns) > eff(best) + 0.05) best = ns;
+    return best;
 }
 
 int check_strides(const char* name, const int64_t* s) {
