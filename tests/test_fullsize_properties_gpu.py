@@ -1,0 +1,128 @@
+"""GPU: the hot-path kernels at BASELINE's full sizes (SDXL 1024² per-GPU batch shapes), checked through
+size-independent properties instead of an oracle that would take minutes on the CPU: softmax rows sum to one,
+linearity in V, key-permutation invariance; a centre-tap 3x3 convolution is a 1x1 linear and a single off-centre
+tap is a shift; GroupNorm output statistics; a zero adapter leaves the base layer untouched and the adapter is
+linear in lora_up; the NF4 GEMM equals the bf16 GEMM on the dequantised weight."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from .helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(gpu, *s, sc=1.0, seed=0):
+    g = torch.Generator(device=gpu).manual_seed(seed)
+    return (torch.randn(*s, generator=g, device=gpu, dtype=torch.float32) * sc).to(torch.bfloat16)
+
+
+def test_attention_properties_at_sdxl_self_attention_size(gpu):
+    from vision_ft_amd import kernels
+
+    B, H, S, D = 4, 10, 4096, 64  # the 64x64-latent level of SDXL at 1024²
+    q, k = _bf(gpu, B, H, S, D, seed=1), _bf(gpu, B, H, S, D, seed=2)
+    v1, v2 = _bf(gpu, B, H, S, D, seed=3), _bf(gpu, B, H, S, D, seed=4)
+    ones = torch.ones(B, H, S, D, device=gpu, dtype=torch.bfloat16)
+    o1 = kernels.flash_attention(q, k, ones)
+    assert (o1.float() - 1).abs().max() < 2e-2  # softmax rows sum to one
+    oa, ob = kernels.flash_attention(q, k, v1), kernels.flash_attention(q, k, v2)
+    oab = kernels.flash_attention(q, k, (v1.float() + v2.float()).to(torch.bfloat16))
+    assert rel_err(oab, oa.float() + ob.float()) < 1e-2  # linear in V
+    perm = torch.randperm(S, device=gpu)
+    op = kernels.flash_attention(q, k[:, :, perm], v1[:, :, perm])
+    assert rel_err(op, oa.float()) < 1e-2  # keys are a set
+    # key-padding: masking the last keys == dropping them
+    kv_len = torch.full((B,), S - 1000, dtype=torch.int32, device=gpu)
+    om = kernels.flash_attention(q, k, v1, kv_len=kv_len)
+    od = kernels.flash_attention(q, k[:, :, : S - 1000].contiguous(), v1[:, :, : S - 1000].contiguous())
+    assert rel_err(om, od.float()) < 5e-3
+
+
+def test_attention_backward_properties_at_full_size(gpu):
+    from vision_ft_amd import kernels
+
+    B, H, S, D = 2, 20, 1024, 64  # the 32x32-latent level
+    q, k, v = (_bf(gpu, B, H, S, D, seed=s).requires_grad_(True) for s in (5, 6, 7))
+    g1, g2 = _bf(gpu, B, H, S, D, seed=8), _bf(gpu, B, H, S, D, seed=9)
+    o = kernels.flash_attention(q, k, v)
+    ga = torch.autograd.grad(o, (q, k, v), g1, retain_graph=True)
+    gb = torch.autograd.grad(o, (q, k, v), g2, retain_graph=True)
+    gab = torch.autograd.grad(o, (q, k, v), (g1.float() + g2.float()).to(torch.bfloat16), retain_graph=True)
+    for x, y, z in zip(ga, gb, gab):
+        assert rel_err(z, x.float() + y.float()) < 1.5e-2  # the vector-Jacobian product is linear in dO
+    # dV = P^T dO: with dO = ones every row of P sums to one, so sum_keys dV == number of queries per (b, h, d)
+    (dv,) = torch.autograd.grad(o, (v,), torch.ones_like(o))
+    assert rel_err(dv.float().sum(2), torch.full((B, H, D), float(S), device=gpu)) < 5e-3
+
+
+def test_conv3x3_properties_at_full_size(gpu):
+    from vision_ft_amd import kernels
+
+    B, C, H = 16, 320, 128  # the 128x128-latent level, per-GPU batch of the bench
+    x = _bf(gpu, B, C, H, H, seed=10).contiguous(memory_format=torch.channels_last)
+    w1 = _bf(gpu, C, C, sc=C**-0.5, seed=11)
+    b = _bf(gpu, C, sc=0.1, seed=12)
+    w = torch.zeros(C, C, 3, 3, device=gpu, dtype=torch.bfloat16)
+    w[:, :, 1, 1] = w1  # only the centre tap: the convolution is a per-pixel linear layer
+    w = w.contiguous(memory_format=torch.channels_last)
+    y = kernels.conv3x3(x, w, b)
+    ref = F.linear(x.permute(0, 2, 3, 1), w1, b).permute(0, 3, 1, 2)
+    assert rel_err(y, ref.float()) < 4e-3
+    # a single off-centre tap with identity channel mixing shifts the image (zero padding at the border)
+    ws = torch.zeros(C, C, 3, 3, device=gpu, dtype=torch.bfloat16)
+    ws[:, :, 0, 2] = torch.eye(C, device=gpu, dtype=torch.bfloat16)
+    ys = kernels.conv3x3(x, ws.contiguous(memory_format=torch.channels_last), None)
+    shifted = torch.zeros_like(x)
+    shifted[:, :, 1:, :-1] = x[:, :, :-1, 1:]  # y[oh, ow] = x[oh - 1, ow + 1]
+    assert torch.equal(ys, shifted)
+    # data gradient of the centre-tap convolution = the transposed linear
+    xg = x.detach().clone().requires_grad_(True)
+    gy = _bf(gpu, B, C, H, H, seed=13).contiguous(memory_format=torch.channels_last)
+    kernels.conv3x3(xg, w, b).backward(gy)
+    refg = (gy.permute(0, 2, 3, 1).float() @ w1.float()).permute(0, 3, 1, 2)
+    assert rel_err(xg.grad, refg) < 4e-3
+
+
+def test_groupnorm_statistics_at_full_size(gpu):
+    from vision_ft_amd import kernels
+
+    B, C, H = 16, 320, 128
+    x = (_bf(gpu, B, C, H, H, seed=14).float() * 3 + 1.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = kernels.group_norm(x, None, None, 32, 1e-5, silu=False)
+    yg = y.float().reshape(B, 32, C // 32, H * H).permute(0, 1, 3, 2).reshape(B, 32, -1)
+    assert yg.mean(-1).abs().max() < 1e-2 and (yg.var(-1) - 1).abs().max() < 2e-2
+    assert y.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_lora_properties_at_full_size(gpu):
+    from vision_ft_amd import kernels
+
+    M, K, N, r = 65536, 640, 5120, 4  # the GEGLU projection of the 64x64 level, B = 16
+    lin = torch.nn.Linear(K, N).to(gpu, torch.bfloat16).requires_grad_(False)
+    x = _bf(gpu, M, K, seed=15)
+    A, B1, B2 = _bf(gpu, r, K, sc=K**-0.5, seed=16), _bf(gpu, N, r, sc=0.3, seed=17), _bf(gpu, N, r, sc=0.3, seed=18)
+    base = lin(x)
+    y0 = kernels.lora_linear(x, lin, A, torch.zeros_like(B1), 0.25)
+    assert torch.equal(y0, base)  # zero-initialised lora_up: the wrapped layer is untouched (reference test_peft.py)
+    d1 = kernels.lora_linear(x, lin, A, B1, 0.25).float() - base.float()
+    d2 = kernels.lora_linear(x, lin, A, B2, 0.25).float() - base.float()
+    d12 = kernels.lora_linear(x, lin, A, (B1.float() + B2.float()).to(torch.bfloat16), 0.25).float() - base.float()
+    assert rel_err(d12, d1 + d2) < 3e-2  # (differences of bf16-rounded outputs: looser)
+
+
+def test_nf4_gemm_equals_bf16_gemm_on_dequantised_weight_at_full_size(gpu):
+    from vision_ft_amd import kernels
+    from vision_ft_amd.modules.quant import NF4Linear, quantize_nf4
+
+    M, out_f, in_f = 17408, 3840, 2304  # Lumina2 fused qkv projection, B = 4
+    w = _bf(gpu, out_f, in_f, sc=0.02, seed=19)
+    q = quantize_nf4(w.float().cpu(), double_quant=True)
+    layer = NF4Linear(in_f, out_f, bias=False)
+    layer.load_state_dict({"weight" + k: v for k, v in q.items()})
+    layer = layer.to(gpu)
+    wd = layer.dequantize()
+    x, gy = _bf(gpu, M, in_f, seed=20), _bf(gpu, M, out_f, seed=21)
+    st = layer.quant_state()
+    assert rel_err(kernels._nf4_gemm(x, st, None, False), (x.float() @ wd.float().t())) < 4e-3
+    assert rel_err(kernels._nf4_gemm(gy, st, None, True), (gy.float() @ wd.float())) < 4e-3
