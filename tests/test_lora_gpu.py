@@ -182,3 +182,45 @@ def test_lora_linear_geglu_fused(gpu, M, C, r):
     assert rel_err(xg.grad.cpu(), xr.grad) < 8e-3, rel_err(xg.grad.cpu(), xr.grad)
     assert rel_err(Ag.grad.cpu(), Ar.grad) < 1.5e-2, rel_err(Ag.grad.cpu(), Ar.grad)
     assert rel_err(Bg.grad.cpu(), Br.grad) < 1.5e-2, rel_err(Bg.grad.cpu(), Br.grad)
+
+
+def test_lora_qkv_fused_projection(gpu):
+    """Three LoRA-wrapped bias-free projections of one input through ONE base GEMM per direction (kernels.lora_qkv)
+    followed by self-attention: outputs and all gradients equal the three separate lora_linear calls."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(21)
+    bf = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16)  # noqa: E731
+    B, S, C, H, r, s = 2, 300, 640, 10, 4, 0.25
+    x = bf(B, S, C)
+    Ws = [bf(C, C, sc=C**-0.5) for _ in range(3)]
+    As = [bf(r, C, sc=C**-0.5) for _ in range(3)]
+    Bs = [bf(C, r, sc=0.3) for _ in range(3)]
+    go = bf(B, H, S, C // H)
+
+    def run(fused: bool):
+        xg = x.to(gpu).requires_grad_(True)
+        Ag = [a.to(gpu).requires_grad_(True) for a in As]
+        Bg = [b.to(gpu).requires_grad_(True) for b in Bs]
+        lins = []
+        for W in Ws:
+            lin = torch.nn.Linear(C, C, bias=False).to(gpu, torch.bfloat16).requires_grad_(False)
+            with torch.no_grad():
+                lin.weight.copy_(W)
+            lins.append(lin)
+        if fused:
+            wqkv = torch.cat([l.weight for l in lins], 0).contiguous()
+            q, k, v = kernels.lora_qkv(xg, wqkv, list(zip(Ag, Bg)), s, H)
+        else:
+            q, k, v = (kernels.lora_linear(xg, l, a, b, s).view(B, S, H, C // H).permute(0, 2, 1, 3)
+                       for l, a, b in zip(lins, Ag, Bg))
+        o = kernels.flash_attention(q, k, v)
+        o.backward(go.to(gpu))
+        return o, xg.grad, [a.grad for a in Ag], [b.grad for b in Bg]
+
+    o1, dx1, dA1, dB1 = run(True)
+    o0, dx0, dA0, dB0 = run(False)
+    assert rel_err(o1, o0.float()) < 2e-3
+    assert rel_err(dx1, dx0.float()) < 1e-2, rel_err(dx1, dx0.float())
+    for a1, a0 in zip(dA1 + dB1, dA0 + dB0):
+        assert rel_err(a1, a0.float()) < 1e-2, rel_err(a1, a0.float())

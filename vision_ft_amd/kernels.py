@@ -126,9 +126,15 @@ class _FlashAttention(torch.autograd.Function):
         B, Hq, Sq, D = q.shape
         _, Hkv, Sk, _ = k.shape
         dout = _as_bhsd(dout.to(torch.bfloat16))
-        dq = _empty_bshd_as_bhsd(B, Hq, Sq, D, q)
-        dk = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
-        dv = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
+        if Hq == Hkv and Sq == Sk:
+            # self-attention: one (B, S, 3, H, D) buffer, so that a fused q|k|v projection gets its output gradient as
+            # a single (tokens, 3*H*D) matrix without a concatenation copy
+            dqkv = torch.empty((B, Sq, 3, Hq, D), dtype=q.dtype, device=q.device)
+            dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        else:
+            dq = _empty_bshd_as_bhsd(B, Hq, Sq, D, q)
+            dk = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
+            dv = _empty_bshd_as_bhsd(B, Hkv, Sk, D, q)
         ws_floats = int(_C.lib().vft_attn_bwd_workspace(B, Hq, Hkv, Sq, Sk, D))
         delta = torch.empty(ws_floats, dtype=torch.float32, device=q.device)  # delta (+ split-Q partials)
         with torch.cuda.device(q.device), _Timed(f"attn_bwd_d{D}", 10.0 * B * Hq * Sq * Sk * D):
@@ -612,6 +618,67 @@ def lora_down(x2: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
         st = _C.lib().vft_lora_down(_ptr(x2), _ptr(A), _ptr(t), M, K, r, x2.stride(0), _stream())
     _C.check(st, "vft_lora_down")
     return t
+
+
+class _LoRAQKV(torch.autograd.Function):
+    """q, k, v = three LoRA-adapted bias-free projections of the same input (SDXL SelfAttention,
+    src/models/sdxl/denoiser.py:32-94) with ONE base GEMM per direction: forward x·[Wq;Wk;Wv]ᵀ into a (tokens, 3C)
+    buffer whose column slices are q | k | v (returned as (B,H,S,D) views: the attention kernel reads them in place),
+    backward [dq|dk|dv]·[Wq;Wk;Wv] in one GEMM (the attention backward already wrote the three gradients into one
+    buffer).  The rank-sized kernels run per projection on the column slices."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, s, heads):
+        Bsz, S, C = x.shape
+        x2 = _rows(x)
+        As = [t.contiguous() for t in (Aq, Ak, Av)]
+        Bs = [t.contiguous() for t in (Bq, Bk, Bv)]
+        N = Bs[0].shape[0]
+        with torch.cuda.device(x.device):
+            y = F.linear(x2, wqkv)  # (M, 3N)
+            ts, Bts = [], []
+            for i in range(3):
+                t, Bt = _lora_fwd_(x2, y[:, i * N:(i + 1) * N], As[i], Bs[i], s)
+                ts.append(t)
+                Bts.append(Bt)
+        ctx.save_for_backward(x2, wqkv, *ts, *Bts, *As, *Bs)
+        ctx.s, ctx.xshape, ctx.N = s, x.shape, N
+        y5 = y.view(Bsz, S, 3, heads, N // heads)
+        return tuple(y5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x2, wqkv = ctx.saved_tensors[:2]
+        ts, Bts, As, Bs = (ctx.saved_tensors[2 + 3 * i: 5 + 3 * i] for i in range(4))
+        s, N = ctx.s, ctx.N
+        M = x2.shape[0]
+        esz = dq.element_size()
+        fused = (dq.dtype == torch.bfloat16 and dq.stride() == dk.stride() == dv.stride() and dq.stride(3) == 1
+                 and dq.stride(1) * dq.shape[1] == N and dq.stride(2) == 3 * N and dq.stride(0) == dq.shape[2] * 3 * N
+                 and dk.data_ptr() == dq.data_ptr() + N * esz and dv.data_ptr() == dq.data_ptr() + 2 * N * esz)
+        if fused:
+            dy = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
+        else:
+            dy = torch.cat([g.permute(0, 2, 1, 3).reshape(M, N) for g in (dq, dk, dv)], dim=1).to(torch.bfloat16)
+        grads = [None] * 6
+        with torch.cuda.device(dy.device):
+            dx2 = dy @ wqkv  # (M, 3N) x (3N, C)
+            for i in range(3):
+                dyi = dy[:, i * N:(i + 1) * N]
+                u = _lora_bwd_dx_(dyi, dx2, Bts[i], As[i], s)
+                if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
+                    grads[2 * i], grads[2 * i + 1] = _lora_wgrad2(x2, u, dyi, ts[i], As[i], Bs[i], s)
+        dx = dx2.view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return (dx, None, *grads, None, None)
+
+
+def lora_qkv(x: torch.Tensor, wqkv: torch.Tensor, adapters, scale: float, heads: int):
+    """(q, k, v) as (B,H,S,D) views for three LoRA-wrapped bias-free projections of `x` (B,S,C);
+    wqkv = cat of the frozen base weights (3N, C); adapters = [(lora_down, lora_up)] * 3."""
+    _ready(x, wqkv)
+    _require_gpu(x, wqkv)
+    (Aq, Bq), (Ak, Bk), (Av, Bv) = adapters
+    return _LoRAQKV.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads))
 
 
 class _QLoRALinear(torch.autograd.Function):

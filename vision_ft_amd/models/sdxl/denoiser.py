@@ -67,10 +67,32 @@ class SelfAttention(nn.Module):
         self.to_v = nn.Linear(self.inner_dim, self.inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(self.inner_dim, self.inner_dim), nn.Dropout(dropout))
 
+    def _fused_qkv_weight(self) -> torch.Tensor | None:
+        """[Wq; Wk; Wv] of the frozen bases when q/k/v are LoRA-wrapped bf16 Linears of one rank (else None):
+        one base GEMM then serves the three projections (kernels.lora_qkv).  Cached; rebuilt if a base changes."""
+        ps = (self.to_q, self.to_k, self.to_v)
+        if not all(isinstance(p, LoRALinear) and p.enabled and not p.training_dropout_active()
+                   and type(p.linear) is nn.Linear and p.linear.bias is None and p.linear.weight.dtype == torch.bfloat16
+                   and not p.linear.weight.requires_grad and p.rank == ps[0].rank and p._scale() == ps[0]._scale() for p in ps):
+            return None
+        key = tuple((p.linear.weight.data_ptr(), p.linear.weight._version) for p in ps)
+        if getattr(self, "_wqkv_key", None) != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self._wqkv = torch.cat([p.linear.weight.detach() for p in ps], dim=0).contiguous()
+            self._wqkv_key = key
+        return self._wqkv
+
     def forward(self, hidden_states: torch.Tensor, mask: torch.Tensor | None = None, residual: torch.Tensor | None = None):
-        q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
-        k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)
-        v = _split_heads(self.to_v(hidden_states), self.num_heads, self.head_dim)
+        wqkv = self._fused_qkv_weight() if hidden_states.is_cuda and hidden_states.dim() == 3 else None
+        if wqkv is not None:
+            q, k, v = kernels.lora_qkv(hidden_states, wqkv,
+                                       [(p.lora_down.weight, p.lora_up.weight) for p in (self.to_q, self.to_k, self.to_v)],
+                                       self.to_q._scale(), self.num_heads)
+        else:
+            q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
+            k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)
+            v = _split_heads(self.to_v(hidden_states), self.num_heads, self.head_dim)
         attn = scaled_dot_product_attention(q, k, v, mask=mask, backend=self.attn_implementation)
         return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
