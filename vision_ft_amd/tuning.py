@@ -29,6 +29,15 @@ def enable(table: str | None = None, tune: bool = False, max_tuning_ms: int = 40
     if not tune and not os.path.exists(table):
         return False
     tunable.enable(True)
+    if not tune:
+        # TunableOp may rewrite its file at process exit; with one process per GPU that would be N writers on the
+        # committed table.  Lookup-only runs therefore work on a private copy.
+        import shutil
+        import tempfile
+
+        private = os.path.join(tempfile.gettempdir(), f"vft_gemm_table_{os.getpid()}.csv")
+        shutil.copyfile(table, private)
+        table = private
     tunable.set_filename(table, insert_device_ordinal=False)
     tunable.tuning_enable(tune)
     if tune:
