@@ -150,7 +150,7 @@ def pmc_traffic(kernel: str):
         for row in csv.DictReader(open(path)):
             if row["kernel"] == kernel:
                 return (round(float(row["traffic_MB"]) * 1e6),
-                        f"bytes/launch at B16 H10 S4096 D64 (the 64x64-latent self-attention); algorithmic {row['algorithmic_MB']} MB")
+                        f"bytes/launch at B24 H10 S4096 D64 (the 64x64-latent self-attention); algorithmic {row['algorithmic_MB']} MB")
     except OSError:
         pass
     return None, None
@@ -191,7 +191,7 @@ def main():
 
     gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
 
-    batch = args.batch or {"sdxl_lora": 16, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4,
+    batch = args.batch or {"sdxl_lora": 24, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4,
                            "sdxl_buckets": 8}[args.workload]
     model = build(args.workload, device)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -261,6 +261,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof_steps = args.steps
+    peak_timed = torch.cuda.max_memory_allocated(device) / 2**30
+    if use_graph:
+        # release the graphs' private pool before the eager timing pass allocates its own activations
+        step = None
+        if args.workload == "sdxl_buckets":
+            graphs.clear()
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
     if use_graph:
         # per-kernel HIP-event timing cannot be recorded inside a graph replay: time the same step
         # eagerly (same process, same tensors) right after the timed region, outside of it.  Every rank
@@ -302,6 +312,7 @@ def main():
             "config": {"workload": args.workload, "resolution": "mixed buckets ~1 MP" if bucket_note else "1024x1024", "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph, "gemm_table": bool(gemm_table),
                        "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5),
+                       "peak_mem_gib": round(peak_timed, 1),
                        **({"buckets": bucket_note} if bucket_note else {}),
                        **({"base_weights": "NF4 (blocksize 64, double-quantised absmax), dequantised in the GEMM kernel"}
                           if args.workload == "lumina_qlora" else {})},

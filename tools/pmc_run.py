@@ -1,5 +1,5 @@
 """Tiny driver for rocprofv3 --pmc passes: runs the dominant hand-written kernels at their headline
-shapes a few times (SDXL self-attention fwd/bwd at B=16, LoRA rows fwd/bwd, wgrad).
+shapes a few times (SDXL self-attention fwd/bwd at B=24, LoRA rows fwd/bwd, wgrad).
    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python3 tools/pmc_run.py"""
 import sys
 
@@ -11,7 +11,7 @@ from vision_ft_amd import kernels  # noqa: E402
 dev = torch.device("cuda:0")
 bf = lambda *s: torch.randn(*s, device=dev, dtype=torch.float32).to(torch.bfloat16)  # noqa: E731
 
-B, H, S, D = 16, 10, 4096, 64
+B, H, S, D = 24, 10, 4096, 64
 q = bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True)
 k = bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True)
 v = bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True)
@@ -19,7 +19,7 @@ do = bf(B, S, H, D).permute(0, 2, 1, 3)
 for _ in range(3):
     kernels.flash_attention(q, k, v).backward(do)
 
-M, K, N, r = 65536, 640, 5120, 4
+M, K, N, r = 98304, 640, 5120, 4
 x, y, dy, dx = bf(M, K), bf(M, N), bf(M, N), bf(M, K)
 A, Bw = bf(r, K), bf(N, r)
 for _ in range(3):
@@ -31,7 +31,7 @@ print("algorithmic bytes: attn_fwd q+k+v+o =", 4 * B * H * S * D * 2, " lora_fwd
       " lora_bwd_dx =", 2 * M * N + 4 * M * K, " lora_wgrad2 =", 2 * M * (K + N))
 
 # implicit-GEMM convolution (SDXL 320->320 at 128x128, B=16) forward + data gradient
-Bc, Ci, Co, Hc = 16, 320, 320, 128
+Bc, Ci, Co, Hc = 24, 320, 320, 128
 xc = bf(Bc, Ci, Hc, Hc).contiguous(memory_format=torch.channels_last).requires_grad_(True)
 wc = (bf(Co, Ci, 3, 3) * 0.02).contiguous(memory_format=torch.channels_last)
 bc = bf(Co)

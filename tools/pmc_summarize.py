@@ -8,13 +8,13 @@ import glob
 import sys
 
 ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
-    "attn_fwd_kernel": 4 * 16 * 10 * 4096 * 64 * 2 / 1e6,
-    "attn_bwd_dq_kernel": 5 * 16 * 10 * 4096 * 64 * 2 / 1e6,
-    "attn_bwd_dkdv_kernel": 6 * 16 * 10 * 4096 * 64 * 2 / 1e6,
-    "lora_rows_kernelILi4ELb1": (2 * 65536 * 640 + 4 * 65536 * 5120) / 1e6,
-    "lora_rows_kernelILi4ELb0": (2 * 65536 * 5120 + 4 * 65536 * 640) / 1e6,
-    "lora_wgrad_partial": 2 * 65536 * (640 + 5120) / 1e6,
-    "linear_kernel": (2 * 16 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6,
+    "attn_fwd_kernel": 4 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "attn_bwd_dq_kernel": 5 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "attn_bwd_dkdv_kernel": 6 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "lora_rows_kernelILi4ELb1": (2 * 98304 * 640 + 4 * 98304 * 5120) / 1e6,
+    "lora_rows_kernelILi4ELb0": (2 * 98304 * 5120 + 4 * 98304 * 640) / 1e6,
+    "lora_wgrad_partial": 2 * 98304 * (640 + 5120) / 1e6,
+    "linear_kernel": (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6,
 }
 
 
