@@ -918,9 +918,6 @@ def _conv3x3_call(x_nhwc: torch.Tensor, w_ohwi: torch.Tensor, bias, B, H, W, Cin
     return y
 
 
-_DGRAD_W: dict = {}  # id(weight) -> (version, data_ptr, flipped/transposed copy) for frozen weights
-
-
 def _dgrad_weight(weight: torch.Tensor) -> torch.Tensor:
     """w'[Cin,3,3,Cout] (storage of a channels-last (Cin,Cout,3,3) tensor) = w[Cout,2-kh,2-kw,Cin]."""
     def make():
@@ -928,12 +925,12 @@ def _dgrad_weight(weight: torch.Tensor) -> torch.Tensor:
 
     if weight.requires_grad:  # full fine-tune: the weight changes every step
         return make()
-    key = id(weight)
-    hit = _DGRAD_W.get(key)
+    # cached on the parameter object itself (lives and dies with it): (version, data_ptr, flipped/transposed copy)
+    hit = getattr(weight, "_vft_dgrad_weight", None)
     if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
         hit = (weight._version, weight.data_ptr(), make())
         if not torch.cuda.is_current_stream_capturing():  # a captured tensor lives in the graph's private pool
-            _DGRAD_W[key] = hit
+            weight._vft_dgrad_weight = hit
     return hit[2]
 
 
