@@ -139,6 +139,23 @@ def cpu_baseline(threads: int) -> dict:
                       f"autocast cpu bf16): 1 warm-up + 2 timed steps, {r['s_per_step']:.2f} s/step"}
 
 
+def per_call_roofline(prof: dict) -> dict:
+    """Algorithmic work / measured time of every hand-written C-ABI call of the step, against the roofline that
+    bounds it: flops vs the dense bf16 MFMA peak for the matrix kernels, bytes vs the HBM peak for the streaming ones
+    (vision_ft_amd/kernels.py passes each call's algorithmic work to its timer)."""
+    out = {}
+    for k, v in prof.items():
+        if v["ms"] <= 0:
+            continue
+        rate = v["work"] / (v["ms"] * 1e-3)
+        mfma = k.startswith(("attn_", "conv3x3", "gemm_", "linear_"))
+        if mfma:
+            out[k] = {"bound": "mfma", "achieved": round(rate / 1e12, 1), "unit": "TFLOP/s", "frac": round(rate / 1e12 / PEAK_BF16_MFMA_TFLOPS, 3)}
+        else:
+            out[k] = {"bound": "hbm", "achieved": round(rate / 1e9), "unit": "GB/s", "frac": round(rate / 1e9 / PEAK_HBM_GBS, 3)}
+    return out
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.csv:
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py, gfx950 x2 fetch
@@ -303,6 +320,7 @@ def main():
                     "gflop_per_launch": round(work / max(n_launch, 1) / 1e9, 2),
                     "launches_per_step": n_launch // max(prof_steps, 1),
                     "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
+                    "per_call": per_call_roofline(prof),
                     "measured": "HIP events around each launch, " + ("eager pass after the graph-replayed timed region" if use_graph else "inside the timed region"),
                     "step_mfma_frac": round(images_s / world * F_ALG[args.workload] / PEAK_BF16_MFMA_TFLOPS, 4)}
         out = {

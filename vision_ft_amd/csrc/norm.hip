@@ -50,16 +50,19 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<bf16x8*>(p) = t;
 }
 
+// NCH = 8-element chunks per lane (compile-time: the row lives in NCH*8 registers, so narrow rows keep the
+// occupancy that hides HBM latency)
+template <int NCH>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(NormParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int C = p.C;
     const bf16_t* xr = p.x + row * p.ldx;
-    float v[MAXCH][8];
+    float v[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int col = (c * 64 + lane) * 8;
         if (col < C) {
             load8(xr + col, v[c]);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(NormParams p) {
     const int64_t bidx = row / p.rpb;
     bf16_t* yr = p.y + row * (int64_t)C;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int col = (c * 64 + lane) * 8;
         if (col < C) {
             float o[8];
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(NormParams p) {
 
 // dx for y = (xhat*w + b)*(1+scale) + shift.   g = dy*(1+scale)*w ;
 //   layer: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) ;  rms: dx = rstd*(g - xhat*mean(g*xhat))
+template <int NCH>
 __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(NormParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -133,10 +137,10 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(NormParams p) {
     const float mean = p.kind == KIND_LAYER ? p.mean[row] : 0.f;
     const float rstd = p.rstd[row];
     const int64_t bidx = row / p.rpb;
-    float xh[MAXCH][8], g[MAXCH][8];
+    float xh[NCH][8], g[NCH][8];
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int col = (c * 64 + lane) * 8;
         if (col < C) {
             load8(xr + col, xh[c]);
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(NormParams p) {
     if (p.kind != KIND_LAYER) sg = 0.f;
     bf16_t* dxr = p.dx + row * (int64_t)C;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int col = (c * 64 + lane) * 8;
         if (col < C) {
             float o[8];
@@ -361,7 +365,14 @@ extern "C" int vft_norm_fwd(const void* x, void* y, const void* weight, const vo
     p.x = (const bf16_t*)x, p.y = (bf16_t*)y, p.w = (const bf16_t*)weight, p.b = (const bf16_t*)bias;
     p.scale = (const bf16_t*)scale, p.shift = (const bf16_t*)shift, p.mean = mean, p.rstd = rstd;
     p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch, p.kind = kind, p.eps = eps;
-    hipLaunchKernelGGL(norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    switch ((C + 511) / 512) {
+#define VFT_NORM_FWD(n) case n: hipLaunchKernelGGL(norm_fwd_kernel<n>, grid, dim3(256), 0, (hipStream_t)stream, p); break
+        VFT_NORM_FWD(1); VFT_NORM_FWD(2); VFT_NORM_FWD(3); VFT_NORM_FWD(4); VFT_NORM_FWD(5); VFT_NORM_FWD(6);
+        case 7: case 8: hipLaunchKernelGGL(norm_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL(norm_fwd_kernel<MAXCH>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+#undef VFT_NORM_FWD
+    }
     VFT_CHECK_LAUNCH("vft_norm_fwd");
     return 0;
 }
@@ -378,7 +389,14 @@ extern "C" int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight
     VFT_CHECK_ARG(dres == nullptr || ((uintptr_t)dres & 15) == 0, "vft_norm_bwd_dx: misaligned residual gradient");
     p.scale = (const bf16_t*)scale, p.mean = const_cast<float*>(mean), p.rstd = const_cast<float*>(rstd);
     p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch, p.kind = kind;
-    hipLaunchKernelGGL(norm_bwd_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    switch ((C + 511) / 512) {
+#define VFT_NORM_BWD(n) case n: hipLaunchKernelGGL(norm_bwd_dx_kernel<n>, grid, dim3(256), 0, (hipStream_t)stream, p); break
+        VFT_NORM_BWD(1); VFT_NORM_BWD(2); VFT_NORM_BWD(3); VFT_NORM_BWD(4); VFT_NORM_BWD(5); VFT_NORM_BWD(6);
+        case 7: case 8: hipLaunchKernelGGL(norm_bwd_dx_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL(norm_bwd_dx_kernel<MAXCH>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+#undef VFT_NORM_BWD
+    }
     VFT_CHECK_LAUNCH("vft_norm_bwd_dx");
     return 0;
 }
