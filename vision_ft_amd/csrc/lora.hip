@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
                                                         int M, int K, int N, int r, int64_t ldx, int64_t ldy, float s) {
     __shared__ float red[4][16][17];
     __shared__ float ps[16][17];
+    __shared__ bf16x2 pt[16][9];  // RC >= 8: the same activations as bf16 pairs
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m0 = blockIdx.x * 16;
     // ---- phase 1 ----
@@ -82,6 +83,15 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
         const int row = tid >> 4, j = tid & 15;
         const float v = red[0][row][j] + red[1][row][j] + red[2][row][j] + red[3][row][j];
         ps[row][j] = v;
+        if (RC >= 8) {  // rank-r activations as bf16 pairs for the packed phase 2 (they are a bf16 tensor in the reference)
+            const float vn = __shfl_down(v, 1, 64);
+            if ((j & 1) == 0) {
+                bf16x2 pr;
+                pr[0] = (bf16_t)v;
+                pr[1] = (bf16_t)vn;
+                pt[row][j >> 1] = pr;
+            }
+        }
         if (p_out != nullptr && j < r && m0 + row < M) p_out[(int64_t)(m0 + row) * r + j] = (bf16_t)v;
     }
     __syncthreads();
@@ -96,6 +106,97 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
     const int rp = 256 / cw;
     const int lr = tid / cw, lc = tid - lr * cw;
     if (lr >= rp) return;
+    if constexpr (RC >= 8) {
+        // Ranks 5..16: coefficients and activations as bf16 pairs, two MACs per v_dot2c_f32_bf16.  Half the VALU
+        // work and half the coefficient registers of the fp32-FMA form (whose 128 coefficient registers at rank
+        // 16 left two waves per SIMD to hide the HBM latency of a read-modify-write stream).
+        constexpr int HP = RC / 2;
+        for (int c0 = 0; c0 < G; c0 += cw) {
+            if (c0 + lc >= G) break;
+            const int n0 = (c0 + lc) * 8;
+            bf16x2 wpk[8][HP];
+            if (NJ) {
+                if (r == RC) {  // the 8 columns' coefficients are one contiguous run of 8*r elements: RC 16-byte loads
+                    bf16x8 wv[RC];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) wv[q] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)n0 * RC + 8 * q);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+#pragma unroll
+                        for (int jj = 0; jj < HP; ++jj) {
+                            bf16x2 t2;
+                            t2[0] = wv[(c * RC + 2 * jj) >> 3][(c * RC + 2 * jj) & 7];
+                            t2[1] = wv[(c * RC + 2 * jj + 1) >> 3][(c * RC + 2 * jj + 1) & 7];
+                            wpk[c][jj] = t2;
+                        }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+#pragma unroll
+                        for (int jj = 0; jj < HP; ++jj) {
+                            bf16x2 t2;
+                            t2[0] = (2 * jj < r) ? w2[(int64_t)(n0 + c) * r + 2 * jj] : (bf16_t)0.f;
+                            t2[1] = (2 * jj + 1 < r) ? w2[(int64_t)(n0 + c) * r + 2 * jj + 1] : (bf16_t)0.f;
+                            wpk[c][jj] = t2;
+                        }
+                }
+                if (w2t_out != nullptr && blockIdx.x == 0 && lr == 0) {
+#pragma unroll
+                    for (int j = 0; j < RC; ++j)
+                        if (j < r) {
+                            bf16x8 v;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) v[c] = wpk[c][j >> 1][j & 1];
+                            *reinterpret_cast<bf16x8*>(w2t_out + (int64_t)j * N + n0) = v;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < HP; ++jj) {
+                    bf16x8 va = zero8(), vb = zero8();
+                    if (2 * jj < r) va = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(2 * jj) * N + n0);
+                    if (2 * jj + 1 < r) vb = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(2 * jj + 1) * N + n0);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        bf16x2 t2;
+                        t2[0] = va[c];
+                        t2[1] = vb[c];
+                        wpk[c][jj] = t2;
+                    }
+                }
+            }
+            for (int i0 = lr; i0 < nrows; i0 += 4 * rp) {
+                bf16x8 v[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = i0 + b * rp;
+                    if (i < nrows) v[b] = *reinterpret_cast<const bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0);
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = i0 + b * rp;
+                    if (i >= nrows) break;
+                    bf16x2 tp[HP];
+#pragma unroll
+                    for (int jj = 0; jj < HP; ++jj) tp[jj] = pt[i][jj];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < HP; ++jj) d = __builtin_amdgcn_fdot2_f32_bf16(wpk[c][jj], tp[jj], d, false);
+                        v[b][c] = (bf16_t)fmaf(s, d, (float)v[b][c]);
+                    }
+                    if (res != nullptr) {
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + (int64_t)(m0 + i) * ldres + n0);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[b][c] = (bf16_t)((float)v[b][c] + (float)rv[c]);
+                    }
+                    *reinterpret_cast<bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0) = v[b];
+                }
+            }
+        }
+        return;
+    }
     for (int c0 = 0; c0 < G; c0 += cw) {
         if (c0 + lc >= G) break;
         const int n0 = (c0 + lc) * 8;
