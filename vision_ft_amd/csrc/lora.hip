@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
                                                         int M, int K, int N, int r, int64_t ldx, int64_t ldy, float s) {
     __shared__ float red[4][16][17];
     __shared__ float ps[16][17];
-    __shared__ bf16x2 pt[16][9];  // RC >= 8: the same activations as bf16 pairs
+    __shared__ bf16x2 pt[16][9];  // the same activations as bf16 pairs
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m0 = blockIdx.x * 16;
     // ---- phase 1 ----
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
         const int row = tid >> 4, j = tid & 15;
         const float v = red[0][row][j] + red[1][row][j] + red[2][row][j] + red[3][row][j];
         ps[row][j] = v;
-        if (RC >= 8) {  // rank-r activations as bf16 pairs for the packed phase 2 (they are a bf16 tensor in the reference)
+        {  // rank-r activations as bf16 pairs for phase 2 (they are a bf16 tensor in the reference)
             const float vn = __shfl_down(v, 1, 64);
             if ((j & 1) == 0) {
                 bf16x2 pr;
@@ -106,10 +106,10 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
     const int rp = 256 / cw;
     const int lr = tid / cw, lc = tid - lr * cw;
     if (lr >= rp) return;
-    if constexpr (RC >= 8) {
-        // Ranks 5..16: coefficients and activations as bf16 pairs, two MACs per v_dot2c_f32_bf16.  Half the VALU
-        // work and half the coefficient registers of the fp32-FMA form (whose 128 coefficient registers at rank
-        // 16 left two waves per SIMD to hide the HBM latency of a read-modify-write stream).
+    {
+        // Coefficients and activations as bf16 pairs, two MACs per v_dot2c_f32_bf16: half the VALU work and half the
+        // coefficient registers of an fp32-FMA form (whose 128 coefficient registers at rank 16 left two waves per
+        // SIMD to hide the HBM latency of a read-modify-write stream).
         constexpr int HP = RC / 2;
         for (int c0 = 0; c0 < G; c0 += cw) {
             if (c0 + lc >= G) break;
@@ -187,81 +187,6 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
                         v[b][c] = (bf16_t)fmaf(s, d, (float)v[b][c]);
                     }
                     if (res != nullptr) {
-                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + (int64_t)(m0 + i) * ldres + n0);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[b][c] = (bf16_t)((float)v[b][c] + (float)rv[c]);
-                    }
-                    *reinterpret_cast<bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0) = v[b];
-                }
-            }
-        }
-        return;
-    }
-    for (int c0 = 0; c0 < G; c0 += cw) {
-        if (c0 + lc >= G) break;
-        const int n0 = (c0 + lc) * 8;
-        for (int j0 = 0; j0 < r; j0 += RC) {
-            float wreg[8][RC];
-            if (NJ) {
-                // w2[n*r + j]: the 8 columns' coefficients are one contiguous run of 8*r elements
-                if (r == RC) {
-                    bf16x8 wv[RC];
-#pragma unroll
-                    for (int q = 0; q < RC; ++q)
-                        wv[q] = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)n0 * RC + 8 * q);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-#pragma unroll
-                        for (int j = 0; j < RC; ++j) wreg[c][j] = s * (float)wv[(c * RC + j) >> 3][(c * RC + j) & 7];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-#pragma unroll
-                        for (int j = 0; j < RC; ++j)
-                            wreg[c][j] = (j0 + j < r) ? s * (float)w2[(int64_t)(n0 + c) * r + j0 + j] : 0.f;
-                }
-                if (w2t_out != nullptr && blockIdx.x == 0 && lr == 0) {
-#pragma unroll
-                    for (int j = 0; j < RC; ++j)
-                        if (j0 + j < r) {
-                            bf16x8 v;
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) v[c] = w2[(int64_t)(n0 + c) * r + j0 + j];
-                            *reinterpret_cast<bf16x8*>(w2t_out + (int64_t)(j0 + j) * N + n0) = v;
-                        }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < RC; ++j) {
-                    bf16x8 v = zero8();
-                    if (j0 + j < r) v = *reinterpret_cast<const bf16x8*>(w2 + (int64_t)(j0 + j) * N + n0);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) wreg[c][j] = s * (float)v[c];
-                }
-            }
-            // rows in batches of 4: all loads of a batch are in flight before the first FMA
-            for (int i0 = lr; i0 < nrows; i0 += 4 * rp) {
-                bf16x8 v[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = i0 + b * rp;
-                    if (i < nrows) v[b] = *reinterpret_cast<const bf16x8*>(y + (int64_t)(m0 + i) * ldy + n0);
-                }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = i0 + b * rp;
-                    if (i >= nrows) break;
-                    float tv[RC];
-#pragma unroll
-                    for (int j = 0; j < RC; ++j) tv[j] = (j0 + j < 16) ? ps[i][(j0 + j) & 15] : 0.f;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float a = (float)v[b][c];
-#pragma unroll
-                        for (int j = 0; j < RC; ++j) a = fmaf(tv[j], wreg[c][j], a);
-                        v[b][c] = (bf16_t)a;
-                    }
-                    if (res != nullptr && j0 + RC >= r) {  // residual add on the rounded layer output, as the reference does
                         const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + (int64_t)(m0 + i) * ldres + n0);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) v[b][c] = (bf16_t)((float)v[b][c] + (float)rv[c]);
