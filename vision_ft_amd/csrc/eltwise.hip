@@ -66,13 +66,17 @@ template <int RC, bool BWD>
 __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restrict__ proj, const bf16_t* __restrict__ t,
                                                          const bf16_t* __restrict__ Bw, const bf16_t* __restrict__ dy,
                                                          bf16_t* __restrict__ out, int M, int F, int r, float s) {
-    __shared__ float ts[16][RC + 1];
+    constexpr int HP = RC / 2;
+    __shared__ bf16x2 ts[16][HP + 1];  // the block's rank-r activations as bf16 pairs
     const int tid = threadIdx.x;
     const int m0 = blockIdx.x * 16;
     const int nrows = min(16, M - m0);
-    if (tid < 16 * RC) {
-        const int row = tid / RC, j = tid % RC;
-        ts[row][j] = (row < nrows && j < r) ? s * (float)t[(int64_t)(m0 + row) * r + j] : 0.f;
+    if (tid < 16 * HP) {
+        const int row = tid / HP, jj = tid % HP;
+        bf16x2 pr;
+        pr[0] = (row < nrows && 2 * jj < r) ? t[(int64_t)(m0 + row) * r + 2 * jj] : (bf16_t)0.f;
+        pr[1] = (row < nrows && 2 * jj + 1 < r) ? t[(int64_t)(m0 + row) * r + 2 * jj + 1] : (bf16_t)0.f;
+        ts[row][jj] = pr;
     }
     __syncthreads();
     const int G = F >> 3;
@@ -84,8 +88,9 @@ __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restric
     for (int c0 = 0; c0 < G; c0 += cw) {
         if (c0 + lc >= G) break;
         const int f0 = (c0 + lc) * 8;
-        float wa[8][RC], wg[8][RC];
-        if (r == RC) {  // the 8 columns' coefficients are one contiguous run of 8*r elements: RC 16-byte loads
+        // coefficients of the thread's 8 value and 8 gate columns as bf16 pairs (two MACs per v_dot2c_f32_bf16)
+        bf16x2 wa[8][HP], wg[8][HP];
+        if (r == RC) {  // contiguous runs of 8*r elements: RC 16-byte loads each
             bf16x8 va[RC], vg[RC];
 #pragma unroll
             for (int q = 0; q < RC; ++q) {
@@ -95,20 +100,30 @@ __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restric
 #pragma unroll
             for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int j = 0; j < RC; ++j) {
-                    wa[c][j] = (float)va[(c * RC + j) >> 3][(c * RC + j) & 7];
-                    wg[c][j] = (float)vg[(c * RC + j) >> 3][(c * RC + j) & 7];
+                for (int jj = 0; jj < HP; ++jj) {
+                    bf16x2 x2, y2;
+                    x2[0] = va[(c * RC + 2 * jj) >> 3][(c * RC + 2 * jj) & 7];
+                    x2[1] = va[(c * RC + 2 * jj + 1) >> 3][(c * RC + 2 * jj + 1) & 7];
+                    y2[0] = vg[(c * RC + 2 * jj) >> 3][(c * RC + 2 * jj) & 7];
+                    y2[1] = vg[(c * RC + 2 * jj + 1) >> 3][(c * RC + 2 * jj + 1) & 7];
+                    wa[c][jj] = x2;
+                    wg[c][jj] = y2;
                 }
         } else {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int j = 0; j < RC; ++j) {
-                    wa[c][j] = j < r ? (float)Bw[(int64_t)(f0 + c) * r + j] : 0.f;
-                    wg[c][j] = j < r ? (float)Bw[(int64_t)(F + f0 + c) * r + j] : 0.f;
+                for (int jj = 0; jj < HP; ++jj) {
+                    bf16x2 x2, y2;
+                    x2[0] = 2 * jj < r ? Bw[(int64_t)(f0 + c) * r + 2 * jj] : (bf16_t)0.f;
+                    x2[1] = 2 * jj + 1 < r ? Bw[(int64_t)(f0 + c) * r + 2 * jj + 1] : (bf16_t)0.f;
+                    y2[0] = 2 * jj < r ? Bw[(int64_t)(F + f0 + c) * r + 2 * jj] : (bf16_t)0.f;
+                    y2[1] = 2 * jj + 1 < r ? Bw[(int64_t)(F + f0 + c) * r + 2 * jj + 1] : (bf16_t)0.f;
+                    wa[c][jj] = x2;
+                    wg[c][jj] = y2;
                 }
         }
-        // rows in batches of NB: every load of a batch is in flight before the first FMA
+        // rows in batches of NB: every load of a batch is in flight before the first MAC
         constexpr int NB = BWD ? 2 : 4;
         for (int i0 = lr; i0 < nrows; i0 += NB * rp) {
             float a[NB][8], g[NB][8], d[BWD ? NB : 1][8];
@@ -127,18 +142,19 @@ __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restric
                 const int i = i0 + b * rp;
                 if (i >= nrows) break;
                 const int64_t m = m0 + i;
-                float tv[RC];
+                bf16x2 tp[HP];
 #pragma unroll
-                for (int j = 0; j < RC; ++j) tv[j] = ts[i][j];
+                for (int jj = 0; jj < HP; ++jj) tp[jj] = ts[i][jj];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
+                    float da_ = 0.f, dg_ = 0.f;
 #pragma unroll
-                    for (int j = 0; j < RC; ++j) {
-                        a[b][c] = fmaf(tv[j], wa[c][j], a[b][c]);
-                        g[b][c] = fmaf(tv[j], wg[c][j], g[b][c]);
+                    for (int jj = 0; jj < HP; ++jj) {
+                        da_ = __builtin_amdgcn_fdot2_f32_bf16(wa[c][jj], tp[jj], da_, false);
+                        dg_ = __builtin_amdgcn_fdot2_f32_bf16(wg[c][jj], tp[jj], dg_, false);
                     }
-                    a[b][c] = (float)(bf16_t)a[b][c];  // the projection output is a bf16 tensor in the reference
-                    g[b][c] = (float)(bf16_t)g[b][c];
+                    a[b][c] = (float)(bf16_t)fmaf(s, da_, a[b][c]);  // the projection output is a bf16 tensor in the reference
+                    g[b][c] = (float)(bf16_t)fmaf(s, dg_, g[b][c]);
                 }
                 if (!BWD) {
                     float o[8];
