@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
         ld8(dy + m * F + c, d);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            da[i] = d[i] * gelu_f(g[i]);
-            dg[i] = d[i] * a[i] * dgelu_f(g[i]);
+            float gl, dgl;
+            gelu_both(g[i], gl, dgl);
+            da[i] = d[i] * gl;
+            dg[i] = d[i] * a[i] * dgl;
         }
         st8(dproj + m * 2 * F + c, da);
         st8(dproj + m * 2 * F + F + c, dg);

@@ -83,10 +83,35 @@ __device__ __forceinline__ float dsilu_f(float x) {
     float s = 1.f / (1.f + __expf(-x));
     return s * (1.f + x * (1.f - s));
 }
+// erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26), branch-free: a third of libm erff's instructions — the GEGLU
+// kernels were VALU-bound on it.  Far below the 2^-9 resolution of the bf16 tensors these functions feed.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
 // exact (erf) GELU as torch.nn.functional.gelu default
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
-    float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
     float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
+}
+// gelu(x) and gelu'(x) sharing one erf and one exp (exp(-x²/2) is also erf_fast's exp((x/√2)²))
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+    const float z = x * 0.70710678118654752f, az = fabsf(z);
+    const float e = __expf(-az * az);  // = exp(-x²/2)
+    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float cdf = 0.5f * (1.f + copysignf(1.f - p * t * e, z));
+    g = x * cdf;
+    dg = fmaf(x * 0.39894228040143268f, e, cdf);
 }
