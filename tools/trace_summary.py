@@ -44,6 +44,8 @@ def main():
             return "conv3x3/linear(ours)"
         if "attn_" in n:
             return "attention(ours)"
+        if "geglu" in n:
+            return "norm/act(ours)"
         if "lora_" in n:
             return "lora(ours)"
         if "gemm_nt" in n or "nf4" in n:
