@@ -337,29 +337,6 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnPa
     }
 }
 
-// =============================================================================================
-// delta[b,h,q] = sum_d O*dO   (one wave per row)
-// =============================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p, int D) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nrows = (int64_t)p.B * p.Hq * p.Sq;
-    if (row >= nrows) return;
-    const int q = (int)(row % p.Sq);
-    const int hq = (int)((row / p.Sq) % p.Hq);
-    const int b = (int)(row / ((int64_t)p.Sq * p.Hq));
-    const bf16_t* o = p.o + b * p.so.b + hq * p.so.h + (int64_t)q * p.so.s;
-    const bf16_t* d = p.dout + b * p.sdo.b + hq * p.sdo.h + (int64_t)q * p.sdo.s;
-    float acc = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        bf16x4 a = *reinterpret_cast<const bf16x4*>(o + c);
-        bf16x4 g = *reinterpret_cast<const bf16x4*>(d + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc += (float)a[j] * (float)g[j];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) p.delta[row] = acc;
-}
 
 // =============================================================================================
 // backward dQ: one workgroup = 128 queries, key tiles of 64
