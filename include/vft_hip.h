@@ -165,8 +165,12 @@ int vft_geglu_bwd(const void* proj, const void* dy, void* dproj, int64_t M, int 
  * sdxl/denoiser.py:183-186). */
 int vft_geglu_lora_fwd(const void* proj, const void* t, const void* lora_up, void* out, int64_t M, int F, int r,
                        float scale, void* stream);
+/* u2 [M][r2], lora_down2 [r2][F], scale2 (optional): the LoRA data gradient of the projection that consumes the GEGLU
+ * output (ff.net.2), applied to dy on the fly (dy + scale2 * u2 . lora_down2) so that layer skips its own
+ * read-modify-write pass over the (M, 4C) gradient. */
 int vft_geglu_lora_bwd(const void* proj, const void* t, const void* lora_up, const void* dy, void* dproj,
-                       int64_t M, int F, int r, float scale, void* stream);
+                       int64_t M, int F, int r, float scale, const void* u2, const void* lora_down2, int r2,
+                       float scale2, void* stream);
 int vft_swiglu_fwd(const void* a, const void* b, void* out, int64_t n, void* stream);
 int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void* db, int64_t n, void* stream);
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,

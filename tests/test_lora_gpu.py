@@ -224,3 +224,35 @@ def test_lora_qkv_fused_projection(gpu):
     assert rel_err(dx1, dx0.float()) < 1e-2, rel_err(dx1, dx0.float())
     for a1, a0 in zip(dA1 + dB1, dA0 + dB0):
         assert rel_err(a1, a0.float()) < 1e-2, rel_err(a1, a0.float())
+
+
+@pytest.mark.parametrize("M,C,r", [(1000, 640, 4), (333, 1280, 8)])
+def test_lora_geglu_down_fused_feedforward(gpu, M, C, r):
+    """x + down(geglu(up(x))) with both adapters folded into the GEGLU kernels (kernels.lora_geglu_down) equals the
+    step-by-step composition (lora_linear -> geglu -> lora_linear with residual): output and every gradient."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(31)
+    bf = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16)  # noqa: E731
+    Fh, s = 4 * C, 0.25
+    x, res = bf(M, C), bf(M, C)
+    up = torch.nn.Linear(C, 2 * Fh).to(gpu, torch.bfloat16).requires_grad_(False)
+    dn = torch.nn.Linear(Fh, C).to(gpu, torch.bfloat16).requires_grad_(False)
+    A1, B1 = bf(r, C, sc=C**-0.5), bf(2 * Fh, r, sc=0.3)
+    A2, B2 = bf(r, Fh, sc=Fh**-0.5), bf(C, r, sc=0.3)
+    gy = bf(M, C)
+
+    def run(fused: bool):
+        xs = x.to(gpu).requires_grad_(True)
+        rs = res.to(gpu).requires_grad_(True)
+        ps = [t.to(gpu).requires_grad_(True) for t in (A1, B1, A2, B2)]
+        if fused:
+            y = kernels.lora_geglu_down(xs, up, ps[0], ps[1], s, dn, ps[2], ps[3], s, residual=rs)
+        else:
+            y = kernels.lora_linear(kernels.geglu(kernels.lora_linear(xs, up, ps[0], ps[1], s)), dn, ps[2], ps[3], s, residual=rs)
+        y.backward(gy.to(gpu))
+        return [y, xs.grad, rs.grad] + [p.grad for p in ps]
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert rel_err(u, v.float()) < 1.2e-2, (i, rel_err(u, v.float()))

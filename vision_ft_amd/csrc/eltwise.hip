@@ -67,9 +67,14 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
 template <int RC, bool BWD>
 __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restrict__ proj, const bf16_t* __restrict__ t,
                                                          const bf16_t* __restrict__ Bw, const bf16_t* __restrict__ dy,
-                                                         bf16_t* __restrict__ out, int M, int F, int r, float s) {
+                                                         bf16_t* __restrict__ out, int M, int F, int r, float s,
+                                                         const bf16_t* __restrict__ u2, const bf16_t* __restrict__ A2, int r2,
+                                                         float s2) {
+    // (BWD only, optional) u2 [M][r2], A2 [r2][F], s2: the consuming projection's LoRA data gradient, applied to dy on
+    // the fly:  dy_eff = dy + s2 * u2 . A2  — that layer then skips its read-modify-write pass over the (M, 4C) gradient
     constexpr int HP = RC / 2;
     __shared__ bf16x2 ts[16][HP + 1];  // the block's rank-r activations as bf16 pairs
+    __shared__ bf16x2 us[16][HP + 1];  // BWD with u2: the block's rows of u2 as bf16 pairs
     const int tid = threadIdx.x;
     const int m0 = blockIdx.x * 16;
     const int nrows = min(16, M - m0);
@@ -79,6 +84,12 @@ __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restric
         pr[0] = (row < nrows && 2 * jj < r) ? t[(int64_t)(m0 + row) * r + 2 * jj] : (bf16_t)0.f;
         pr[1] = (row < nrows && 2 * jj + 1 < r) ? t[(int64_t)(m0 + row) * r + 2 * jj + 1] : (bf16_t)0.f;
         ts[row][jj] = pr;
+        if (BWD && u2 != nullptr) {
+            bf16x2 pu;
+            pu[0] = (row < nrows && 2 * jj < r2) ? u2[(int64_t)(m0 + row) * r2 + 2 * jj] : (bf16_t)0.f;
+            pu[1] = (row < nrows && 2 * jj + 1 < r2) ? u2[(int64_t)(m0 + row) * r2 + 2 * jj + 1] : (bf16_t)0.f;
+            us[row][jj] = pu;
+        }
     }
     __syncthreads();
     const int G = F >> 3;
@@ -125,6 +136,24 @@ __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restric
                     wg[c][jj] = y2;
                 }
         }
+        bf16x2 wd[8][HP];  // BWD with u2: A2[2jj .. 2jj+1][f0 + c]
+        if (BWD && u2 != nullptr) {
+#pragma unroll
+            for (int jj = 0; jj < HP; ++jj) {
+                bf16x8 ra, rb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[e] = rb[e] = (bf16_t)0.f;
+                if (2 * jj < r2) ra = *reinterpret_cast<const bf16x8*>(A2 + (int64_t)(2 * jj) * F + f0);
+                if (2 * jj + 1 < r2) rb = *reinterpret_cast<const bf16x8*>(A2 + (int64_t)(2 * jj + 1) * F + f0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    bf16x2 t2;
+                    t2[0] = ra[c];
+                    t2[1] = rb[c];
+                    wd[c][jj] = t2;
+                }
+            }
+        }
         // rows in batches of NB: every load of a batch is in flight before the first MAC
         constexpr int NB = BWD ? 2 : 4;
         for (int i0 = lr; i0 < nrows; i0 += NB * rp) {
@@ -164,11 +193,25 @@ __global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restric
                     for (int c = 0; c < 8; ++c) o[c] = a[b][c] * gelu_f(g[b][c]);
                     st8(out + m * F + f0, o);
                 } else {
+                    if (u2 != nullptr) {
+                        bf16x2 up[HP];
+#pragma unroll
+                        for (int jj = 0; jj < HP; ++jj) up[jj] = us[i][jj];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            float dd = 0.f;
+#pragma unroll
+                            for (int jj = 0; jj < HP; ++jj) dd = __builtin_amdgcn_fdot2_f32_bf16(wd[c][jj], up[jj], dd, false);
+                            d[b][c] = fmaf(s2, dd, d[b][c]);
+                        }
+                    }
                     float da[8], dg[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        da[c] = d[b][c] * gelu_f(g[b][c]);
-                        dg[c] = d[b][c] * a[b][c] * dgelu_f(g[b][c]);
+                        float gl, dgl;
+                        gelu_both(g[b][c], gl, dgl);
+                        da[c] = d[b][c] * gl;
+                        dg[c] = d[b][c] * a[b][c] * dgl;
                     }
                     st8(out + m * 2 * F + f0, da);
                     st8(out + m * 2 * F + F + f0, dg);
@@ -296,26 +339,32 @@ extern "C" int vft_geglu_lora_fwd(const void* proj, const void* t, const void* l
     const dim3 grid((unsigned)((M + 15) / 16));
     if (r <= 4)
         hipLaunchKernelGGL((geglu_lora_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale);
+                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale, nullptr, nullptr, 0, 0.f);
     else
         hipLaunchKernelGGL((geglu_lora_kernel<8, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale);
+                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale, nullptr, nullptr, 0, 0.f);
     VFT_CHECK_LAUNCH("vft_geglu_lora_fwd");
     return 0;
 }
 
 // dproj[M][2F] from dy[M][F], recomputing the adapted projection
 extern "C" int vft_geglu_lora_bwd(const void* proj, const void* t, const void* lora_up, const void* dy, void* dproj, int64_t M,
-                                  int F, int r, float scale, void* stream) {
+                                  int F, int r, float scale, const void* u2, const void* lora_down2, int r2, float scale2,
+                                  void* stream) {
     if (geglu_lora_args("vft_geglu_lora_bwd", proj, t, lora_up, dproj, M, F, r)) return 1;
     VFT_CHECK_ARG(dy != nullptr && ((uintptr_t)dy & 15) == 0, "vft_geglu_lora_bwd: bad dy pointer");
+    VFT_CHECK_ARG((u2 == nullptr) == (lora_down2 == nullptr), "vft_geglu_lora_bwd: u2 and lora_down2 go together");
+    VFT_CHECK_ARG(u2 == nullptr || (r2 > 0 && r2 <= (r <= 4 ? 4 : 8) && ((uintptr_t)lora_down2 & 15) == 0),
+                  "vft_geglu_lora_bwd: the consumer's rank (%d) must fit this launch's rank chunk and lora_down2 be 16-byte aligned", r2);
     const dim3 grid((unsigned)((M + 15) / 16));
     if (r <= 4)
         hipLaunchKernelGGL((geglu_lora_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale);
+                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale,
+                           (const bf16_t*)u2, (const bf16_t*)lora_down2, r2, scale2);
     else
         hipLaunchKernelGGL((geglu_lora_kernel<8, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale);
+                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale,
+                           (const bf16_t*)u2, (const bf16_t*)lora_down2, r2, scale2);
     VFT_CHECK_LAUNCH("vft_geglu_lora_bwd");
     return 0;
 }

@@ -788,9 +788,73 @@ class _GeGLULoRA(torch.autograd.Function):
         dproj = torch.empty((M, F2), dtype=torch.bfloat16, device=dy.device)
         with torch.cuda.device(dy.device), _Timed("geglu_bwd", 10.0 * M * Fh):
             st = _C.lib().vft_geglu_lora_bwd(_ptr(p2), _ptr(t), _ptr(B), _ptr(dy2), _ptr(dproj), M, Fh, B.shape[1],
-                                             float(ctx.s), _stream())
+                                             float(ctx.s), None, None, 0, 0.0, _stream())
         _C.check(st, "vft_geglu_lora_bwd")
         return dproj.view(ctx.pshape), None, None, None
+
+
+class _GeGLUDown(torch.autograd.Function):
+    """out = residual + LoRALinear_2(geglu(proj + s1·t1·B1ᵀ)) — the GEGLU and the FeedForward's output projection
+    (SDXL FeedForward.net[0..2], src/models/sdxl/denoiser.py:175-207) as one autograd node, so that the backward can
+    hand the output projection's LoRA data gradient to the GEGLU backward kernel (`u2`, `A2`): neither adapter
+    costs a read-modify-write pass over a (tokens, 4C/8C) tensor.  d(proj) flows on to `_LoRALinearDeferred`."""
+
+    @staticmethod
+    def forward(ctx, proj, t1, B1, s1, W2, b2, A2, B2, s2, residual):
+        F2 = proj.shape[-1]
+        p2 = _rows(proj)
+        if p2.stride(0) != F2:
+            p2 = p2.contiguous()
+        M, Fh = p2.shape[0], F2 // 2
+        B1, A2, B2 = B1.contiguous(), A2.contiguous(), B2.contiguous()
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(-1, residual.shape[-1])
+            if res2.stride(-1) != 1 or res2.stride(0) % 8 != 0 or res2.dtype != torch.bfloat16:
+                res2 = res2.to(torch.bfloat16).contiguous()
+        g = torch.empty((M, Fh), dtype=torch.bfloat16, device=proj.device)
+        with torch.cuda.device(proj.device):
+            with _Timed("geglu_fwd", 6.0 * M * Fh):
+                st = _C.lib().vft_geglu_lora_fwd(_ptr(p2), _ptr(t1), _ptr(B1), _ptr(g), M, Fh, B1.shape[1], float(s1), _stream())
+            _C.check(st, "vft_geglu_lora_fwd")
+            y2 = F.linear(g, W2, b2)
+            t2, _ = _lora_fwd_(g, y2, A2, B2, s2, res2)
+        ctx.save_for_backward(p2, t1, B1, g, t2, W2, A2, B2)
+        ctx.s1, ctx.s2, ctx.pshape = s1, s2, proj.shape
+        ctx.res_shape = residual.shape if residual is not None else None
+        return y2.view(*proj.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        p2, t1, B1, g, t2, W2, A2, B2 = ctx.saved_tensors
+        M, F2 = p2.shape
+        Fh = F2 // 2
+        dy2 = _rows(dy)
+        if dy2.dtype != torch.bfloat16 or dy2.stride(-1) != 1:
+            dy2 = dy2.to(torch.bfloat16).contiguous()
+        dA2 = dB2 = None
+        with torch.cuda.device(dy.device):
+            u2 = lora_down(dy2, B2.t().contiguous())       # (M, r2) = dy . B2
+            dg = dy2 @ W2                                   # base data gradient of the output projection, (M, 4C)
+            dproj = torch.empty((M, F2), dtype=torch.bfloat16, device=dy.device)
+            with _Timed("geglu_bwd", 10.0 * M * Fh):
+                st = _C.lib().vft_geglu_lora_bwd(_ptr(p2), _ptr(t1), _ptr(B1), _ptr(dg), _ptr(dproj), M, Fh, B1.shape[1],
+                                                 float(ctx.s1), _ptr(u2), _ptr(A2), A2.shape[0], float(ctx.s2), _stream())
+            _C.check(st, "vft_geglu_lora_bwd")
+            if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
+                dA2, dB2 = _lora_wgrad2(g, u2, dy2, t2, A2, B2, ctx.s2)
+        dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[9] else None
+        return dproj.view(ctx.pshape), None, None, None, None, None, dA2, dB2, None, dres
+
+
+def lora_geglu_down(x: torch.Tensor, up_base, up_A, up_B, s1: float, down_base, down_A, down_B, s2: float,
+                    residual: torch.Tensor | None = None) -> torch.Tensor:
+    """residual + down(geglu(up(x))) for two LoRA-wrapped bf16 Linears (the SDXL FeedForward), fused as described in
+    `_GeGLUDown` / `_LoRALinearDeferred`."""
+    _ready(x, up_A, up_B, down_A, down_B)
+    _require_gpu(x, up_A, up_B, down_A, down_B)
+    proj, t1 = _LoRALinearDeferred.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1))
+    return _GeGLUDown.apply(proj, t1, up_B.detach(), float(s1), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual)
 
 
 def lora_geglu_eligible(x: torch.Tensor, base, lora_down_w: torch.Tensor) -> bool:

@@ -150,6 +150,17 @@ class FeedForward(nn.Module):
                                  nn.Linear(self.intermediate_dim, hidden_dim, bias=True))
 
     def forward(self, hidden_states: torch.Tensor, residual: torch.Tensor | None = None) -> torch.Tensor:
+        up, down = self.net[0].proj, self.net[2]
+        if (FUSE_LORA_INTO_GEGLU and isinstance(up, LoRALinear) and isinstance(down, LoRALinear) and up.enabled and down.enabled
+                and not up.training_dropout_active() and not down.training_dropout_active()
+                and not (isinstance(self.net[1], nn.Dropout) and self.net[1].p > 0 and self.training)
+                and kernels.lora_geglu_eligible(hidden_states, up.linear, up.lora_down.weight)
+                and type(down.linear) is nn.Linear and down.linear.weight.dtype == torch.bfloat16
+                and down.rank <= (4 if up.rank <= 4 else 8)):
+            # up projection (deferred adapter) -> GEGLU applying it -> down projection, one autograd node for the last two:
+            # both adapters' wide read-modify-write passes disappear (kernels._GeGLUDown)
+            return kernels.lora_geglu_down(hidden_states, up.linear, up.lora_down.weight, up.lora_up.weight, up._scale(),
+                                           down.linear, down.lora_down.weight, down.lora_up.weight, down._scale(), residual)
         return _proj_residual(self.net[2], self.net[1](self.net[0](hidden_states)), residual)
 
 
