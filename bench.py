@@ -208,7 +208,7 @@ def main():
 
     gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
 
-    batch = args.batch or {"sdxl_lora": 24, "sdxl_full": 8, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4,
+    batch = args.batch or {"sdxl_lora": 24, "sdxl_full": 16, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4,
                            "sdxl_buckets": 8}[args.workload]
     model = build(args.workload, device)
     params = [p for p in model.parameters() if p.requires_grad]
