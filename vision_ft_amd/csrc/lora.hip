@@ -12,6 +12,8 @@
 //                                                           for backward) and Bᵀ (so backward's dy·B is
 //                                                           again a k-contiguous product).
 //   vft_lora_bwd_dx  dx[M,K] += s · (dy[M,N] · B) · A       same structure; emits u = dy·B.
+//   vft_lora_down    t[M,r]  = x[M,K] · Aᵀ                  phase 1 alone, for consumers that apply the update
+//                                                           themselves (GEGLU kernels, GEMM rank extension).
 //   vft_lora_wgrad2  dA = s · uᵀ x,  dB = s · dyᵀ t         both weight gradients in one launch pair
 //                                                           (partials per 256-row block, then a
 //                                                           deterministic reduce).
@@ -42,7 +44,8 @@ __device__ __forceinline__ bf16x8 zero8() {
 //   phase 1:  p[16][r] = X[16 rows][K] · Wᵀ,  W = w1[r][K] row-major (k contiguous)
 //   phase 2:  Y[16 rows][N] += s · p · W2,    W2(j, n):  NJ layout  w2[n*r + j]   (fwd: lora_up (N,r))
 //                                                        JN layout  w2[j*N + n]   (bwd: lora_down (r,K))
-// RC = rank chunk held in registers (>= r for the shipped ranks 4 / 8 / 16).
+// RC = 4 / 8 / 16 >= r: the rank padded to the register tile; phase 2 keeps coefficients and activations as bf16
+// pairs (v_dot2c_f32_bf16).  N == 0 (vft_lora_down): phase 1 only.
 // ---------------------------------------------------------------------------------------------
 template <int RC, bool NJ>
 __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
