@@ -661,13 +661,19 @@ class _LoRAQKV(torch.autograd.Function):
         else:
             dy = torch.cat([g.permute(0, 2, 1, 3).reshape(M, N) for g in (dq, dk, dv)], dim=1).to(torch.bfloat16)
         grads = [None] * 6
+        r = As[0].shape[0]
         with torch.cuda.device(dy.device):
             dx2 = dy @ wqkv  # (M, 3N) x (3N, C)
+            if 3 * r <= 16:
+                # the three adapters' data gradients in ONE pass over dy and dx: u = dy · blockdiag(Bq,Bk,Bv)
+                # (M, 3r), dx += s · u · [Aq;Ak;Av] — the rank-3r instance of the same kernel
+                u_all = _lora_bwd_dx_(dy, dx2, torch.block_diag(*Bts), torch.cat(list(As), 0), s)
+                us = [u_all[:, i * r:(i + 1) * r].contiguous() for i in range(3)]
+            else:
+                us = [_lora_bwd_dx_(dy[:, i * N:(i + 1) * N], dx2, Bts[i], As[i], s) for i in range(3)]
             for i in range(3):
-                dyi = dy[:, i * N:(i + 1) * N]
-                u = _lora_bwd_dx_(dyi, dx2, Bts[i], As[i], s)
                 if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
-                    grads[2 * i], grads[2 * i + 1] = _lora_wgrad2(x2, u, dyi, ts[i], As[i], Bs[i], s)
+                    grads[2 * i], grads[2 * i + 1] = _lora_wgrad2(x2, us[i], dy[:, i * N:(i + 1) * N], ts[i], As[i], Bs[i], s)
         dx = dx2.view(ctx.xshape) if ctx.needs_input_grad[0] else None
         return (dx, None, *grads, None, None)
 
