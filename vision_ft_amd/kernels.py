@@ -668,12 +668,23 @@ class _LoRAQKV(torch.autograd.Function):
                 # the three adapters' data gradients in ONE pass over dy and dx: u = dy · blockdiag(Bq,Bk,Bv)
                 # (M, 3r), dx += s · u · [Aq;Ak;Av] — the rank-3r instance of the same kernel
                 u_all = _lora_bwd_dx_(dy, dx2, torch.block_diag(*Bts), torch.cat(list(As), 0), s)
-                us = [u_all[:, i * r:(i + 1) * r].contiguous() for i in range(3)]
+                us = None
             else:
                 us = [_lora_bwd_dx_(dy[:, i * N:(i + 1) * N], dx2, Bts[i], As[i], s) for i in range(3)]
-            for i in range(3):
-                if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
-                    grads[2 * i], grads[2 * i + 1] = _lora_wgrad2(x2, us[i], dy[:, i * N:(i + 1) * N], ts[i], As[i], Bs[i], s)
+            if 3 * r <= 16 and all(ctx.needs_input_grad[2:8]):
+                # both weight gradients of the three adapters in one launch pair: dA_cat (3r, C) = u_allᵀ · x (x read
+                # once instead of three times); dB_all (3N, 3r) = dyᵀ · t_all, of which the diagonal blocks are dB_i
+                A_cat, B_all = torch.cat(list(As), 0), torch.block_diag(*Bs)
+                dA_cat, dB_all = _lora_wgrad2(x2, u_all, dy, torch.cat(list(ts), 1), A_cat, B_all, s)
+                for i in range(3):
+                    grads[2 * i] = dA_cat[i * r:(i + 1) * r]
+                    grads[2 * i + 1] = dB_all[i * N:(i + 1) * N, i * r:(i + 1) * r]
+            else:
+                if us is None:
+                    us = [u_all[:, i * r:(i + 1) * r].contiguous() for i in range(3)]
+                for i in range(3):
+                    if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
+                        grads[2 * i], grads[2 * i + 1] = _lora_wgrad2(x2, us[i], dy[:, i * N:(i + 1) * N], ts[i], As[i], Bs[i], s)
         dx = dx2.view(ctx.xshape) if ctx.needs_input_grad[0] else None
         return (dx, None, *grads, None, None)
 
