@@ -248,3 +248,42 @@ def test_product_never_imports_oracle():
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
     for path in list(pathlib.Path("train").rglob("*.py")):
         assert "oracle" not in path.read_text(), path
+
+
+# ---- bench / tuning helpers (no GPU) ------------------------------------------------------------
+def test_per_call_roofline_classifies_and_divides():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = {"attn_fwd_d64": {"work": 2.5e12, "ms": 2.0, "launches": 1}, "lora_fwd": {"work": 4.0e9, "ms": 1.0, "launches": 1},
+            "idle": {"work": 1.0, "ms": 0.0, "launches": 0}}
+    out = bench.per_call_roofline(prof)
+    assert out["attn_fwd_d64"] == {"bound": "mfma", "achieved": 1250.0, "unit": "TFLOP/s", "frac": 0.5}
+    assert out["lora_fwd"]["bound"] == "hbm" and out["lora_fwd"]["achieved"] == 4000 and out["lora_fwd"]["frac"] == 0.5
+    assert "idle" not in out
+
+
+def test_gemm_table_is_well_formed_and_lookup_runs_on_a_private_copy(tmp_path, monkeypatch):
+    """The committed TunableOp table parses (validators + one solution per key) and `tuning.enable()` never points
+    TunableOp at the committed file for lookup-only runs (N ranks would otherwise rewrite it at exit)."""
+    import tempfile
+
+    from vision_ft_amd import tuning
+
+    rows = [ln.strip().split(",") for ln in open(tuning.DEFAULT_TABLE) if ln.strip()]
+    assert sum(r[0] == "Validator" for r in rows) >= 4
+    keys = [(r[0], r[1]) for r in rows if r[0] != "Validator"]
+    assert len(keys) == len(set(keys)) and len(keys) > 100
+    assert all(len(r) == 4 and float(r[3]) > 0 for r in rows if r[0] != "Validator")
+    calls = {}
+    import torch.cuda.tunable as tunable
+
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    monkeypatch.setattr(tunable, "enable", lambda v=True: calls.__setitem__("enable", v))
+    monkeypatch.setattr(tunable, "tuning_enable", lambda v=True: calls.__setitem__("tuning", v))
+    monkeypatch.setattr(tunable, "set_filename", lambda f, insert_device_ordinal=False: calls.__setitem__("file", f))
+    assert tuning.enable() is True
+    assert calls["enable"] is True and calls["tuning"] is False
+    assert calls["file"].startswith(str(tmp_path)) and open(calls["file"]).read() == open(tuning.DEFAULT_TABLE).read()
