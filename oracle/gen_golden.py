@@ -215,7 +215,9 @@ def lora_train_steps(model, call, peft_include, rank, target_fn, steps=3):
     return torch.stack(losses), keys
 
 
-def gen_sdxl():
+def gen_sdxl(hw=(16, 16), fname="sdxl_tiny.safetensors", seed=42, sizes=None):
+    """hw = latent (height, width).  The default writes the square fixture of round 1 unchanged; `gen_sdxl_rect`
+    writes two non-square buckets (BASELINE config 5: mixed aspect-ratio buckets)."""
     cfgm = importlib.import_module("src.models.sdxl.config")
     den = importlib.import_module("src.models.sdxl.denoiser")
     from src.modules.loss import diffusion as LD
@@ -223,17 +225,18 @@ def gen_sdxl():
     cfg = cfgm.DenoiserConfig(**TINY_SDXL)
     model = den.Denoiser(cfg)
     cs = load_synth(model, seed=0)
-    g = torch.Generator().manual_seed(42)
+    g = torch.Generator().manual_seed(seed)
     B = 2
+    sizes = sizes or dict(original_size=[[512, 512], [768, 640]], target_size=[[512, 512], [704, 640]], crop=[[0, 0], [32, 0]])
     T = {
-        "latents": torch.randn(B, 4, 16, 16, generator=g),
-        "noise": torch.randn(B, 4, 16, 16, generator=g),
+        "latents": torch.randn(B, 4, *hw, generator=g),
+        "noise": torch.randn(B, 4, *hw, generator=g),
         "timestep": torch.tensor([17, 803], dtype=torch.int32),
         "ehs": torch.randn(B, 11, 64, generator=g),
         "pooled": torch.randn(B, 1280, generator=g),
-        "original_size": torch.tensor([[512, 512], [768, 640]]),
-        "target_size": torch.tensor([[512, 512], [704, 640]]),
-        "crop": torch.tensor([[0, 0], [32, 0]]),
+        "original_size": torch.tensor(sizes["original_size"]),
+        "target_size": torch.tensor(sizes["target_size"]),
+        "crop": torch.tensor(sizes["crop"]),
     }
     noisy = LD.prepare_noised_latents(T["latents"], T["timestep"])  # only for the alpha table; redo with stored noise
     ac = (1.0 - torch.linspace(0.00085**0.5, 0.012**0.5, 1000, dtype=torch.float32) ** 2).cumprod(0)
@@ -266,8 +269,17 @@ def gen_sdxl():
     T["lora.losses"] = losses
     meta = {"config": json.dumps(TINY_SDXL), "checksum": repr(cs), "lora_keys": json.dumps(keys),
             "n_state_keys": str(len(shapes_of(den.Denoiser(cfg))))}
-    save_file(t2c(T), os.path.join(OUT, "sdxl_tiny.safetensors"), metadata=meta)
-    print("sdxl: loss", float(T["loss"]), "lora losses", losses.tolist(), "n lora keys", len(keys))
+    save_file(t2c(T), os.path.join(OUT, fname), metadata=meta)
+    print(fname, "loss", float(T["loss"]), "lora losses", losses.tolist(), "n lora keys", len(keys))
+
+
+def gen_sdxl_rect():
+    """Two non-square aspect-ratio buckets of the tiny UNet (latent 16x24 = "tall 128x192 px", 24x16 = its transpose):
+    the (h, w) order of every reshape / conv / up- and down-sampling is pinned against the reference."""
+    gen_sdxl(hw=(16, 24), fname="sdxl_tiny_h16w24.safetensors", seed=52,
+             sizes=dict(original_size=[[128, 192], [200, 260]], target_size=[[128, 192], [128, 192]], crop=[[0, 0], [8, 16]]))
+    gen_sdxl(hw=(24, 16), fname="sdxl_tiny_h24w16.safetensors", seed=53,
+             sizes=dict(original_size=[[192, 128], [300, 210]], target_size=[[192, 128], [192, 128]], crop=[[0, 0], [0, 24]]))
 
 
 def gen_aura():
@@ -317,9 +329,16 @@ def gen_aura():
             model, call, [".attn.", ".mlp"], 4,
             lambda o: LF.loss_with_predicted_velocity(T["latents"], T["noise"], o))
         T["lora.losses"] = losses
+        # BASELINE config 3 trains rank 16: same model, fresh instance, rank-16 adapters
+        model16 = den.Denoiser(cfg)
+        load_synth(model16, seed=1)
+        losses16, keys16 = lora_train_steps(
+            model16, call, [".attn.", ".mlp"], 16,
+            lambda o: LF.loss_with_predicted_velocity(T["latents"], T["noise"], o))
+        T["lora16.losses"] = losses16
         meta = {"config": json.dumps(kw), "checksum": repr(cs), "lora_keys": json.dumps(keys)}
         save_file(t2c(T), os.path.join(OUT, f"aura_tiny{tag}.safetensors"), metadata=meta)
-        print(f"aura{tag}: loss", float(T["loss"]), "lora losses", losses.tolist(), len(keys))
+        print(f"aura{tag}: loss", float(T["loss"]), "lora losses", losses.tolist(), len(keys), "rank16", losses16.tolist())
 
 
 def gen_lumina():
@@ -379,6 +398,60 @@ def gen_lumina():
     meta = {"config": json.dumps(TINY_LUMINA), "checksum": repr(cs), "lora_keys": json.dumps(keys)}
     save_file(t2c(T), os.path.join(OUT, "lumina_tiny.safetensors"), metadata=meta)
     print("lumina: loss", float(T["loss"]), "lora losses", losses.tolist(), len(keys))
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_samplers():
+    """Train-time timestep samplers (src/modules/timestep/sampling.py, src/models/lumina2/scheduler.py:48-72).  The
+    raw draws are stored next to the outputs (never rely on RNG stream equality): the reference functions
+    call torch.randn / torch.rand / torch.randint / np.random.choice exactly once, so re-seeding and making the same call
+    reproduces the draw they consumed."""
+    from src.modules.timestep import sampling as S
+
+    sched = importlib.import_module("src.models.lumina2.scheduler")
+    dev = torch.device("cpu")
+    T = {}
+    B = 16
+    shapes = {"sq": (B, 16, 128, 128), "tall": (B, 16, 192, 80), "small": (B, 4, 32, 48)}
+
+    def draw(kind, seed):
+        torch.manual_seed(seed)
+        return {"randn": lambda: torch.randn(B, device=dev), "rand": lambda: torch.rand(B, device=dev),
+                "randint": lambda: torch.randint(low=0, high=1000, size=(B,), device=dev, dtype=torch.int)}[kind]()
+
+    def run(name, kind, seed, fn):
+        T[f"{name}.draw"] = draw(kind, seed)
+        torch.manual_seed(seed)
+        T[f"{name}.out"] = fn()
+
+    run("sigmoid_randn", "randn", 1, lambda: S.sigmoid_randn(torch.Size(shapes["sq"]), dev))
+    run("sigmoid_randn_s2", "randn", 2, lambda: S.sigmoid_randn(torch.Size(shapes["sq"]), dev, sigmoid_scale=2.0))
+    run("shift_sigmoid_randn", "randn", 3, lambda: S.shift_sigmoid_randn(torch.Size(shapes["sq"]), dev))
+    run("flux_shift_randn_sq", "randn", 4, lambda: S.flux_shift_randn(torch.Size(shapes["sq"]), dev))
+    run("flux_shift_randn_small", "randn", 5, lambda: S.flux_shift_randn(torch.Size(shapes["small"]), dev))
+    run("scale_shift_sigmoid_randn", "randn", 6, lambda: S.scale_shift_sigmoid_randn(torch.Size(shapes["sq"]), dev))
+    run("uniform_rand", "rand", 7, lambda: S.uniform_rand(torch.Size(shapes["sq"]), dev))
+    run("shift_uniform_rand", "rand", 8, lambda: S.shift_uniform_rand(torch.Size(shapes["sq"]), dev))
+    run("uniform_randint", "randint", 9, lambda: S.uniform_randint(torch.Size(shapes["sq"]), dev))
+    for tag in ("sq", "tall", "small"):
+        run(f"lumina_lognorm_{tag}", "randn", 10, lambda: sched.Scheduler().sample_sigmoid_randn(torch.Size(shapes[tag]), dev, patch_size=2))
+    for name, typ, kw in [("dispatch_sigmoid", "sigmoid", {}), ("dispatch_shift", "shift_sigmoid", {"discrete_flow_shift": 2.0}),
+                          ("dispatch_flux", "flux_shift", {})]:
+        run(name, "randn", 11, lambda: S.sample_timestep(torch.Size(shapes["sq"]), dev, typ, **kw))
+    # fraction samplers: numpy global RNG (sampling.py:137); the candidate table and the picks are stored
+    div = [20, 25, 30, 32]
+    T["fraction.table"] = torch.from_numpy(S._create_fraction(div).copy())
+    np.random.seed(12)
+    picks = np.random.choice(S._create_fraction(div), size=B, replace=True)
+    T["fraction.draw"] = torch.from_numpy(picks.copy())
+    np.random.seed(12)
+    T["fraction.out"] = S.fraction_uniform_rand(torch.Size(shapes["sq"]), dev, divisible=div)
+    np.random.seed(12)
+    T["shift_fraction.out"] = S.shift_fraction_uniform_rand(torch.Size(shapes["sq"]), dev, shift=6.0, divisible=div)
+    T["fraction.table_default"] = torch.from_numpy(S._create_fraction(list(range(20, 30))).copy())
+    save_file(t2c(T), os.path.join(OUT, "samplers.safetensors"),
+              metadata={"shapes": json.dumps(shapes), "divisible": json.dumps(div), "batch": str(B)})
+    print("samplers:", len(T), "tensors")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -536,7 +609,8 @@ def gen_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     import_reference()
-    which = sys.argv[1:] or ["ops", "index", "sdxl", "aura", "lumina"]
+    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "aura", "lumina", "samplers"]
     torch.set_num_threads(8)
     for w in which:
-        {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "aura": gen_aura, "lumina": gen_lumina}[w]()
+        {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "sdxl_rect": gen_sdxl_rect, "aura": gen_aura, "lumina": gen_lumina,
+         "samplers": gen_samplers}[w]()

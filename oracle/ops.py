@@ -169,3 +169,54 @@ def linear(P: dict, name: str, x: torch.Tensor) -> torch.Tensor:
 
 def conv2d(P: dict, name: str, x: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
     return F.conv2d(x, P[f"{name}.weight"], P.get(f"{name}.bias"), stride=stride, padding=padding)
+
+
+# ------------------------------------------------------------------------------------------
+# train-time timestep samplers as VALUE TRANSFORMS of a stored raw draw
+# (src/modules/timestep/sampling.py:10-92,148-162,191-207; src/models/lumina2/scheduler.py:48-72).
+# The reference draws with torch.randn / torch.rand / torch.randint / np.random.choice and then applies these.
+# ------------------------------------------------------------------------------------------
+def _lin(x, x1=256.0, y1=0.5, x2=4096.0, y2=1.15):
+    slope = (y2 - y1) / (x2 - x1)
+    return slope * x + (y1 - slope * x1)
+
+
+def sampler_transform(name: str, draw: torch.Tensor, latents_shape=None, **kw) -> torch.Tensor:
+    if name == "sigmoid_randn":  # :70-81
+        return (draw * kw.get("sigmoid_scale", 1.0)).sigmoid()
+    if name == "shift_sigmoid_randn":  # :50-67
+        s = kw.get("discrete_flow_shift", 3.1825)
+        t = (draw * kw.get("sigmoid_scale", 1.0)).sigmoid()
+        return (t * s) / (1 + (s - 1) * t)
+    if name == "flux_shift_randn":  # :34-47
+        _b, _c, h, w = latents_shape
+        t = (draw * kw.get("sigmoid_scale", 1.0)).sigmoid()
+        mu = _lin((h // 2) * (w // 2))
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** 1.0)
+    if name == "scale_shift_sigmoid_randn":  # :259-272
+        return (draw * kw.get("std", 0.8) + kw.get("mean", -0.8)).sigmoid()
+    if name == "uniform_rand":  # :84-92
+        return draw
+    if name in ("shift_uniform_rand", "shift_fraction_uniform_rand"):  # :95-106, :148-162
+        s = kw.get("shift", 6.0)
+        return (draw * s) / (1 + (s - 1) * draw)
+    if name == "uniform_randint":  # :191-207
+        return draw.int()
+    if name == "lumina_lognorm":  # lumina2/scheduler.py:48-72
+        _b, _c, h, w = latents_shape
+        ps = kw.get("patch_size", 2)
+        mu = _lin((h // ps) * (w // ps))
+        t = 1 - draw.sigmoid()
+        t = math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** kw.get("sigma", 1.0))
+        return 1 - t
+    raise ValueError(name)
+
+
+def create_fraction(denominators):  # sampling.py:110-125 (set iteration order = insertion history of the floats)
+    import numpy as np
+
+    uniq = set()
+    for d in denominators:
+        for i in range(0, d + 1):
+            uniq.add(i / d)
+    return np.array(list(uniq), dtype=np.float32)

@@ -43,7 +43,7 @@ def autocast_cpu():
     return torch.autocast("cpu", dtype=torch.bfloat16)
 
 
-def add_lora_params(P: dict[str, torch.Tensor], lora_keys: list[str], seed: int = 11, dtype=torch.bfloat16) -> dict[str, torch.Tensor]:
+def add_lora_params(P: dict[str, torch.Tensor], lora_keys: list[str], seed: int = 11, dtype=torch.bfloat16, rank: int = 4) -> dict[str, torch.Tensor]:
     """Rewrite a flat base state dict into the reference's LoRA-wrapped layout for `lora_keys`
     (the sorted adapter key list stored in the fixture): `<n>.weight` -> `<n>.linear.weight`, plus
     synthetic `<n>.lora_down.weight` (bf16), zero `<n>.lora_up.weight`, `<n>.alpha` = 1."""
@@ -55,7 +55,6 @@ def add_lora_params(P: dict[str, torch.Tensor], lora_keys: list[str], seed: int 
         P[f"{n}.linear.weight"] = w
         if f"{n}.bias" in P:
             P[f"{n}.linear.bias"] = P.pop(f"{n}.bias")
-        rank = 4
         shapes[f"{n}.lora_down.weight"] = (rank, w.shape[1])
         shapes[f"{n}.lora_up.weight"] = (w.shape[0], rank)
     synth = fw.synth_state_dict(shapes, seed=seed)

@@ -287,3 +287,28 @@ def test_gemm_table_is_well_formed_and_lookup_runs_on_a_private_copy(tmp_path, m
     assert tuning.enable() is True
     assert calls["enable"] is True and calls["tuning"] is False
     assert calls["file"].startswith(str(tmp_path)) and open(calls["file"]).read() == open(tuning.DEFAULT_TABLE).read()
+
+
+def test_mask_to_kv_len_accepts_only_prefix_key_padding_masks():
+    """The kernel masks by per-batch key counts; the reference accepts arbitrary masks (src/modules/attention.py:121-129),
+    so whatever cannot be represented must raise instead of attending to the wrong keys."""
+    from vision_ft_amd.modules.attention import mask_to_kv_len
+
+    lens = torch.tensor([7, 3, 0, 5])
+    km = torch.arange(7)[None, :] < lens[:, None]
+    assert mask_to_kv_len(km, 4, 7).tolist() == [7, 3, 0, 5]
+    assert mask_to_kv_len(km.view(4, 1, 1, 7), 4, 7).dtype == torch.int32
+    assert mask_to_kv_len(km.view(4, 1, 1, 7).expand(-1, 6, 9, -1), 4, 7).tolist() == [7, 3, 0, 5]
+    holes = km.clone()
+    holes[0, 2] = False  # same count as a prefix of 6, different keys
+    with pytest.raises(ValueError, match="prefix"):
+        mask_to_kv_len(holes, 4, 7)
+    suffix = torch.arange(7)[None, :] >= torch.tensor([2, 2, 2, 2])[:, None]
+    with pytest.raises(ValueError, match="prefix"):
+        mask_to_kv_len(suffix, 4, 7)
+    with pytest.raises(ValueError):  # per-query mask (not broadcast over queries)
+        mask_to_kv_len(km.view(4, 1, 1, 7).expand(-1, 6, 9, -1).contiguous(), 4, 7)
+    with pytest.raises(ValueError):
+        mask_to_kv_len(km.float(), 4, 7)
+    with pytest.raises(ValueError):
+        mask_to_kv_len(km, 3, 7)

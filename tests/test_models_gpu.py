@@ -53,13 +53,13 @@ def _truth_grads(forward_loss, P, grad_names, x):
     return {n: Pt[n].grad for n in grad_names}, xt.grad, loss.detach()
 
 
-def _lora_train_gpu(model, include, forward_loss, lora_keys, steps=3):
+def _lora_train_gpu(model, include, forward_loss, lora_keys, steps=3, rank=4):
     from vision_ft_amd.modules.peft import LoRAConfig, PeftTargetConfig
 
     from oracle import fixture_weights as fw
 
     model.requires_grad_(False)
-    PeftTargetConfig(include_keys=include, config=LoRAConfig(rank=4, alpha=1.0)).replace_to_peft_layer(model)
+    PeftTargetConfig(include_keys=include, config=LoRAConfig(rank=rank, alpha=1.0)).replace_to_peft_layer(model)
     sd = model.state_dict()
     got_keys = sorted(k for k in sd if ".lora_" in k or k.endswith(".alpha"))
     assert got_keys == lora_keys  # same modules wrapped, same adapter key names as the reference
@@ -81,11 +81,14 @@ def _lora_train_gpu(model, include, forward_loss, lora_keys, steps=3):
     return torch.stack(losses)
 
 
-def test_sdxl_denoiser_parity(gpu):
+@pytest.mark.parametrize("fixture", ["sdxl_tiny", "sdxl_tiny_h16w24", "sdxl_tiny_h24w16"])
+def test_sdxl_denoiser_parity(gpu, fixture):
+    """Square bucket plus two non-square aspect-ratio buckets (BASELINE config 5) against the oracle and the
+    reference's own golden outputs."""
     from vision_ft_amd.models.sdxl import Denoiser, DenoiserConfig
     from vision_ft_amd.modules.loss.diffusion import loss_with_predicted_noise
 
-    T, meta = load_golden("sdxl_tiny.safetensors")
+    T, meta = load_golden(fixture + ".safetensors")
     cfgd = json.loads(meta["config"])
     with torch.device("meta"):
         shape_mod = Denoiser(DenoiserConfig(**cfgd))
@@ -129,6 +132,27 @@ def test_sdxl_denoiser_parity(gpu):
         lambda m: loss_with_predicted_noise(g["latents"], g["noise"], call(m, T["noisy"].to(gpu)).float()),
         json.loads(meta["lora_keys"]))
     torch.testing.assert_close(losses, T["lora.losses"], rtol=LOSS_RTOL, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["", "_rope"])
+def test_auraflow_lora_rank16_losses(gpu, tag):
+    """BASELINE config 3 trains rank-16 adapters: three AdamW steps at rank 16 vs the reference's golden losses."""
+    from vision_ft_amd.models.auraflow import Denoiser, DenoiserConfig
+    from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity
+
+    T, meta = load_golden(f"aura_tiny{tag}.safetensors")
+    cfgd = json.loads(meta["config"])
+    with torch.device("meta"):
+        shape_mod = Denoiser(DenoiserConfig(**cfgd))
+    Pb = {k: v.to(torch.bfloat16).float() for k, v in synth_params(shape_mod, 1, meta["checksum"]).items()}
+    model = _to_gpu_module(Denoiser, DenoiserConfig(**cfgd), Pb, gpu)
+    g = {k: T[k].to(gpu) for k in ("timestep", "ehs", "noise", "latents", "noisy")}
+    losses = _lora_train_gpu(
+        model, [".attn.", ".mlp"],
+        lambda m: loss_with_predicted_velocity(
+            g["latents"], g["noise"], m(latent=g["noisy"], encoder_hidden_states=g["ehs"], timestep=g["timestep"]).float()),
+        json.loads(meta["lora_keys"]), rank=16)
+    torch.testing.assert_close(losses, T["lora16.losses"], rtol=LOSS_RTOL, atol=0)
 
 
 @pytest.mark.parametrize("tag", ["", "_rope"])

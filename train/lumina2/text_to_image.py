@@ -12,16 +12,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 from vision_ft_amd.config import TrainConfig  # noqa: E402
 from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig  # noqa: E402
-from vision_ft_amd.models.lumina2 import Denoiser, Lumina2Config  # noqa: E402
+from vision_ft_amd.models.lumina2 import Denoiser, Lumina2Config, Scheduler  # noqa: E402
 from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity, prepare_noised_latents  # noqa: E402
-from vision_ft_amd.modules.timestep.sampling import uniform_rand  # noqa: E402
+from vision_ft_amd.modules.timestep.sampling import shift_fraction_uniform_rand, uniform_rand  # noqa: E402
 from vision_ft_amd.trainer.common import Trainer  # noqa: E402
 from vision_ft_amd.trainer.tasks import DenoiserTask  # noqa: E402
 
 
 class Lumina2ForTextToImageTrainingConfig(Lumina2Config):
     max_token_length: int = 256
-    timestep_sampling: Literal["uniform"] = "uniform"
+    timestep_sampling: Literal["uniform", "lognorm", "shift_fraction_uniform"] = "uniform"
+    timestep_fraction_divisible: list[int] = [20, 25, 30, 32]
     # the reference's default `use_lowres_loss: true` crashes (tuple added to a tensor,
     # train/lumina2/text_to_image.py:207-216); its shipped YAML sets false, which is the only mode here
     use_lowres_loss: bool = False
@@ -45,9 +46,23 @@ class Lumina2ForTextToImageTraining(DenoiserTask):
         return {"caption": torch.randn(batch, L, self.model_config.denoiser.caption_dim, generator=g, device=dev).to(torch.bfloat16),
                 "mask": torch.arange(L, device=dev).unsqueeze(0) < lens.unsqueeze(1)}
 
+    def sample_timesteps(self, latents_shape: torch.Size) -> torch.Tensor:
+        """train/lumina2/text_to_image.py:144-171 of the reference: the `timestep_sampling` switch."""
+        kind, dev = self.model_config.timestep_sampling, self.accelerator.device
+        if kind == "uniform":
+            return uniform_rand(latents_shape, dev)
+        if kind == "lognorm":
+            return self.scheduler.sample_sigmoid_randn(latents_shape, dev, patch_size=self.model_config.denoiser.patch_size)
+        if kind == "shift_fraction_uniform":  # host-side numpy draw: this mode cannot be replayed from a HIP graph
+            return 1 - shift_fraction_uniform_rand(latents_shape, dev, shift=self.scheduler.shift,
+                                                   divisible=self.model_config.timestep_fraction_divisible)
+        raise ValueError(f"Unknown timestep sampling method: {kind}. ")
+
+    scheduler = Scheduler()
+
     def denoise_loss(self, latents, cond):
         # reference forward_and_loss :100-142: Lumina2 time runs 0 (noise) -> 1 (clean); prediction sign flipped
-        t = uniform_rand(latents.shape, latents.device)
+        t = self.sample_timesteps(latents.shape)
         noisy, noise = prepare_noised_latents(latents, (1 - t).to(latents.dtype))
         out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"])
         pred = -torch.nested.to_padded_tensor(out, padding=0.0)

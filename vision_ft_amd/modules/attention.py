@@ -31,12 +31,16 @@ is_xformers_available = False
 def mask_to_kv_len(mask: torch.Tensor, batch: int, sk: int) -> torch.Tensor:
     """(B,Sk) / (B,1,1,Sk) / (B,H,Sq,Sk)-expanded bool key-padding mask -> (B,) int32 lengths.
 
-    Raises ValueError if the mask is not a per-batch *prefix* mask over keys (checked on device
-    without a host sync only for the cheap structural part: shape/stride; the prefix property is
-    the caller's contract and is verified in tests)."""
+    The kernel masks by length, so the mask must be a per-batch *prefix* mask over keys, broadcast over heads and
+    queries.  The reference (src/modules/attention.py:121-136) hands arbitrary masks to SDPA; anything this kernel
+    cannot represent therefore raises ``ValueError`` instead of silently attending to the wrong keys.  The prefix
+    test reads one flag back from the device, so this entry cannot be used while a HIP graph is being captured: hot
+    paths that build their own lengths (Lumina2) pass ``kv_len=`` instead."""
     if mask.dtype != torch.bool:
         raise ValueError("only boolean key-padding masks are supported by the HIP attention kernel")
     if mask.dim() == 2:
+        if mask.shape != (batch, sk):
+            raise ValueError(f"mask shape {tuple(mask.shape)} does not match (B={batch}, Sk={sk})")
         km = mask
     elif mask.dim() == 4:
         if mask.shape[0] != batch or mask.shape[-1] != sk:
@@ -47,7 +51,14 @@ def mask_to_kv_len(mask: torch.Tensor, batch: int, sk: int) -> torch.Tensor:
         km = mask[:, 0, 0, :]
     else:
         raise ValueError("attention mask must have rank 2 or 4")
-    return km.sum(dim=-1, dtype=torch.int32)
+    kv_len = km.sum(dim=-1, dtype=torch.int32)
+    if mask.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise ValueError("a mask= cannot be validated during HIP-graph capture; pass kv_len= (per-batch key counts) instead")
+    is_prefix = (km == (torch.arange(sk, device=km.device).unsqueeze(0) < kv_len.unsqueeze(1))).all()
+    if not bool(is_prefix):
+        raise ValueError("the HIP attention kernel supports key-padding masks whose valid keys form a prefix "
+                         "(mask[b, :len_b] all True, the rest False); got a mask with holes")
+    return kv_len
 
 
 def scaled_dot_product_attention(
