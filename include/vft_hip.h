@@ -209,6 +209,10 @@ int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void* bias, int
 int vft_linear_fwd(const void* x, const void* w, void* y, const void* bias, const void* residual,
                    const void* ext_x, const void* ext_w, int M, int N, int K, int r, int64_t ldx,
                    int64_t ldw, int64_t ldy, int64_t ldres, void* stream);
+/* Tuning / A-B control of the kernel behind vft_linear_fwd and vft_conv3x3_fwd (process-wide, not thread-safe; the
+ * trainers never call it): 0 = automatic choice (default), -1 = first-generation kernel (linear.hip),
+ * 1 / 2 / 3 = second-generation kernel (linear8.hip) with a 256x256 / 256x128 / 128x128 output tile. */
+int vft_linear_variant(int variant);
 
 /* ---- GEMM (bf16 / NF4 weight) ----------------------------------------------------------------
  * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, weight B row-major [out,in]

@@ -81,3 +81,24 @@ def test_flat_gradient_buffer_follows_parameter_layout():
     assert net.c.weight.is_contiguous(memory_format=torch.channels_last)
     assert net.c.weight.grad.stride() == net.c.weight.stride() and torch.equal(net.c.weight.grad, before)
     assert net.c.weight.grad.untyped_storage().data_ptr() == next(iter(fb.buffers.values())).untyped_storage().data_ptr()
+
+
+def test_nf4_linear_dtype_only_conversion_keeps_the_payload_where_it_is():
+    """`.to(dtype)` / `.float()` on a model holding NF4 layers must not move the packed weight (it used to be probed
+    with a CPU tensor, which dragged a GPU-resident payload to the CPU); device moves still move everything."""
+    import torch
+
+    from vision_ft_amd.modules.quant import NF4Linear, quantize_nf4
+
+    w = torch.randn(64, 128)
+    layer = NF4Linear(128, 64, bias=True)
+    layer.load_state_dict({**{"weight" + k: v for k, v in quantize_nf4(w, double_quant=True).items()}, "bias": torch.zeros(64)})
+    packed = layer.weight.clone()
+    layer.to(torch.float32)
+    assert layer.weight.dtype == torch.uint8 and torch.equal(layer.weight, packed) and layer.bias.dtype == torch.float32
+    layer.to(torch.bfloat16)
+    assert layer.weight.device.type == "cpu" and layer.absmax.device.type == "cpu" and layer.bias.dtype == torch.bfloat16
+    m = layer.to("meta")
+    assert m.weight.device.type == "meta" and m.absmax.device.type == "meta" and m.quant_map.device.type == "meta"
+    m.to(torch.float32)  # dtype-only conversion of a meta-resident layer: nothing is copied out of meta
+    assert m.weight.device.type == "meta" and m.weight.dtype == torch.uint8

@@ -137,20 +137,55 @@ def gemm():
 def linear():
     import torch.nn.functional as F
 
-    print("== fused linear (vft_linear_fwd) vs hipBLASLt F.linear; +lora = rank-4 extension fused vs F.linear + lora_fwd pass ==")
-    for M, N, K in [(65536, 640, 640), (65536, 5120, 640), (65536, 640, 2560), (16384, 1280, 1280), (16384, 10240, 1280),
-                    (16384, 1280, 5120), (65536, 640, 5760), (16384, 1280, 11520), (262144, 320, 2880), (8720, 3072, 3072)]:
+    from vision_ft_amd import _C
+
+    print("== fused linear (vft_linear_fwd): first-generation kernel (v-1), lin8 256x256 / 256x128 / 128x128 (v1-3), auto (v0) vs "
+          "hipBLASLt F.linear; TFLOP/s; +ext = rank-4 extension and residual fused (auto) ==")
+    shapes = [(65536, 640, 640), (65536, 5120, 640), (65536, 640, 2560), (16384, 1280, 1280), (16384, 10240, 1280),
+              (16384, 1280, 5120), (98304, 640, 640), (98304, 1920, 640), (98304, 5120, 640), (98304, 640, 2560),
+              (24576, 1280, 1280), (24576, 3840, 1280), (24576, 10240, 1280), (24576, 1280, 5120), (8720, 3072, 3072),
+              (17440, 3072, 3072), (17440, 8192, 3072), (17440, 3072, 8192), (17408, 3840, 2304), (17408, 2304, 9216)]
+    if len(sys.argv) > 2:
+        shapes = shapes[: int(sys.argv[2])]
+    for M, N, K in shapes:
         x, w, b = bf(M, K), bf(N, K) * 0.05, bf(N)
-        ex, ew = bf(M, 4), bf(N, 4)
-        y = kernels.linear_fused(x, w, b)
+        ex, ew, res = bf(M, 4), bf(N, 4), bf(M, N)
         ref = F.linear(x, w, b)
-        err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
-        to = timeit(lambda: kernels.linear_fused(x, w, b), iters=10)
-        te = timeit(lambda: kernels.linear_fused(x, w, b, ext_x=ex, ext_w=ew), iters=10)
         tl = timeit(lambda: F.linear(x, w, b), iters=10)
         fl = 2.0 * M * N * K
-        print(f"M={M:6d} N={N:5d} K={K:5d} | ours {to*1e6:8.1f} us {fl/to/1e12:7.1f} TF/s | +ext {te*1e6:8.1f} us | hipBLASLt {tl*1e6:8.1f} us "
-              f"{fl/tl/1e12:7.1f} TF/s | rel err {err:.2e}", flush=True)
+        line = f"M={M:6d} N={N:5d} K={K:5d} | hipBLASLt {fl/tl/1e12:6.1f}"
+        for v in (-1, 1, 2, 3, 0):
+            _C.lib().vft_linear_variant(v)
+            y = kernels.linear_fused(x, w, b)
+            err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+            to = timeit(lambda: kernels.linear_fused(x, w, b), iters=10)
+            line += f" | v{v} {fl/to/1e12:6.1f}" + (f" (err {err:.1e})" if err > 1e-3 else "")
+        te = timeit(lambda: kernels.linear_fused(x, w, b, ext_x=ex, ext_w=ew, residual=res), iters=10)
+        line += f" | +ext+res {te*1e6:7.1f} us vs plain {to*1e6:7.1f} us"
+        print(line, flush=True)
+
+
+def conv():
+    from vision_ft_amd import _C
+
+    print("== conv3x3 implicit GEMM: first-generation kernel vs lin8 configs; TFLOP/s ==")
+    for B, H, W, Cin, Cout in [(24, 128, 128, 320, 320), (24, 128, 128, 640, 320), (24, 64, 64, 640, 640), (24, 64, 64, 1280, 640),
+                               (24, 64, 64, 1920, 640), (24, 32, 32, 1280, 1280), (24, 32, 32, 2560, 1280), (24, 64, 64, 320, 640)]:
+        x = bf(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+        w = (bf(Cout, Cin, 3, 3) * 0.05).contiguous(memory_format=torch.channels_last)
+        b = bf(Cout)
+        fl = 18.0 * B * H * W * Cin * Cout
+        _C.lib().vft_linear_variant(-1)
+        ref = kernels._conv3x3_call(x, w, b, B, H, W, Cin, Cout, "conv")
+        line = f"B={B} {H}x{W} {Cin:4d}->{Cout:4d}"
+        for v in (-1, 1, 2, 3, 0):
+            _C.lib().vft_linear_variant(v)
+            y = kernels._conv3x3_call(x, w, b, B, H, W, Cin, Cout, "conv")
+            err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+            to = timeit(lambda: kernels._conv3x3_call(x, w, b, B, H, W, Cin, Cout, "conv"), iters=10)
+            line += f" | v{v} {fl/to/1e12:6.1f}" + (f" (err {err:.1e})" if err > 1e-3 else "")
+        print(line, flush=True)
+    _C.lib().vft_linear_variant(0)
 
 
 if __name__ == "__main__":
@@ -167,3 +202,5 @@ if __name__ == "__main__":
         gemm()
     if which in ("linear", "all"):
         linear()
+    if which in ("conv", "all"):
+        conv()

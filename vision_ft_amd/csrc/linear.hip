@@ -26,10 +26,15 @@
 // projections to the tuned library (vision_ft_amd/tuning.py) — this kernel is the base for the fused
 // epilogues (LoRA, residual, NF4) once its main loop closes the remaining gap.
 #include "vft_common.h"
+#include "linear8.h"
 
 namespace {
 
 constexpr int NTHREADS = 512;
+
+// kernel choice override for tuning / A-B runs (vft_linear_variant): 0 = automatic, -1 = first-generation kernel,
+// 1..3 = second-generation kernel (linear8.hip) with that tile configuration
+int g_variant = 0;
 
 
 struct LinParams {
@@ -493,6 +498,12 @@ void launch_linear(const LinParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int vft_linear_variant(int variant) {
+    VFT_CHECK_ARG(variant >= -1 && variant <= 3, "vft_linear_variant: %d is not in -1..3", variant);
+    g_variant = variant;
+    return 0;
+}
+
 extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void* bias, const void* residual,
                               const void* ext_x, const void* ext_w, int M, int N, int K, int r, int64_t ldx, int64_t ldw,
                               int64_t ldy, int64_t ldres, void* stream) {
@@ -510,6 +521,14 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y, p.bias = (const bf16_t*)bias;
     p.res = (const bf16_t*)residual, p.ex = (const bf16_t*)ext_x, p.ew = (const bf16_t*)ext_w;
     p.M = M, p.N = N, p.K = K, p.r = ext_x ? r : 0, p.ldx = ldx, p.ldw = ldw, p.ldy = ldy, p.ldres = ldres;
+    Lin8Params q{};
+    q.x = p.x, q.w = p.w, q.y = p.y, q.bias = p.bias, q.res = p.res, q.ex = p.ex, q.ew = p.ew;
+    q.M = M, q.N = N, q.K = K, q.r = p.r, q.ldx = ldx, q.ldw = ldw, q.ldy = ldy, q.ldres = ldres;
+    if (g_variant >= 0 && vft_lin8_fits(q, false)) {
+        vft_lin8_launch(q, g_variant > 0 ? g_variant : vft_lin8_pick(M, N, K), false, (hipStream_t)stream);
+        VFT_CHECK_LAUNCH("vft_linear_fwd");
+        return 0;
+    }
     // wide tile when N fills it (>= 75 % of the last 256-wide tile column is real work)
     // 64-deep stages (full 128-byte lines per DMA row) whenever K allows: 5-15 % faster than 32-deep ones
     const int rem = N % 256;
@@ -546,6 +565,15 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.y = (bf16_t*)y, p.bias = (const bf16_t*)bias;
     p.M = B * H * W, p.N = Cout, p.K = 9 * Cin, p.r = 0, p.ldx = Cin, p.ldw = 9 * (int64_t)Cin, p.ldy = Cout, p.ldres = 0;
     p.cH = H, p.cW = W, p.cC = Cin;
+    Lin8Params q{};
+    q.x = p.x, q.w = p.w, q.y = p.y, q.bias = p.bias;
+    q.M = p.M, q.N = p.N, q.K = p.K, q.r = 0, q.ldx = p.ldx, q.ldw = p.ldw, q.ldy = p.ldy, q.ldres = 0;
+    q.cH = H, q.cW = W, q.cC = Cin;
+    if (Cin % 64 == 0 && g_variant >= 0 && vft_lin8_fits(q, true)) {
+        vft_lin8_launch(q, g_variant > 0 ? g_variant : vft_lin8_pick(p.M, p.N, p.K), true, (hipStream_t)stream);
+        VFT_CHECK_LAUNCH("vft_conv3x3_fwd");
+        return 0;
+    }
     const int rem = Cout % 256;
     const bool wide = Cout >= 1024 && (rem == 0 || rem > 192);
     if (Cin % 64 == 0 && Cout >= 640) {  // (the 320-channel layers measure the same or slightly better 32-deep)

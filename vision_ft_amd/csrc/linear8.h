@@ -1,0 +1,29 @@
+// Internal interface between linear.hip (C-ABI entry points, argument checks, kernel choice) and linear8.hip
+// (the second-generation main loop).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vft_common.h"
+
+struct Lin8Params {
+    const bf16_t* x;     // [M][ldx]   (CONV: [B*H*W][ldx = Cin], gathered per tap)
+    const bf16_t* w;     // [N][ldw]
+    bf16_t* y;           // [M][ldy]
+    const bf16_t* bias;  // [N] or null
+    const bf16_t* res;   // [M][ldres] or null
+    const bf16_t* ex;    // [M][r] or null
+    const bf16_t* ew;    // [N][r]
+    int M, N, K, r;
+    int64_t ldx, ldw, ldy, ldres;
+    int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
+    int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
+};
+
+// true when the operands fit the 32-bit offsets of the buffer descriptors (otherwise: first-generation kernel)
+bool vft_lin8_fits(const Lin8Params& p, bool conv);
+
+// cfg: 1 = 256x256 tile (128 KiB LDS), 2 = 256x128 (96 KiB), 3 = 128x128 (64 KiB, two workgroups per CU).  K % 64 == 0.
+void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st);
+// tile configuration with the least last-round loss for an (M, N) problem on 256 CUs
+int vft_lin8_pick(int M, int N, int K);

@@ -1,0 +1,508 @@
+// Projection GEMM, second generation ("lin8"): bf16, fp32 accumulate, gfx950.
+//
+//   y[M,N] = x[M,K] · W[N,K]ᵀ  (+ bias[N])  (+ ex[M,r] · ew[N,r]ᵀ)  (+ res[M,N])          K % 64 == 0
+//
+// Same contract as linear.hip's first-generation kernel (the reference's LoRALinear.forward,
+// src/modules/peft/lora.py:92-104, as ONE launch: base GEMM + bias + rank-r update + residual add; the data
+// gradient is the same call on the transposed frozen weight), and the same implicit-GEMM convolution mode
+// (src/models/sdxl/denoiser.py:511-551).  What changed is the main loop, which now follows the CDNA4 playbook's
+// 8-phase structure:
+//
+//   * 256x256 (or 256x128 / 128x128) output tile, 8 waves, K in tiles of 64 (full 128-byte lines).
+//   * v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it than on 32x32x16 at equal cycles/flop),
+//     weight = A operand, so an accumulator register group is 4 consecutive output features of one token.
+//   * Each K-tile is staged as FOUR half-tiles (X0, W0, W1, X1: rows 0..BM/2, BM/2..BM of x, likewise W) by LDS-DMA
+//     (global_load_lds_dwordx4).  A wave's output tile takes WM/2 rows from EACH X half and WN/2 columns from each
+//     W half, so the four phases of a K-tile — the quadrants (X0,W0) (X0,W1) (X1,W1) (X1,W0) — free the half-tile
+//     slots one after the other and every phase re-fills exactly one slot:
+//         phase 0  reads X0, W0      issues X1 of tile t+1
+//         phase 1  reads W1          issues X0 of tile t+2      (X0's slot was last read one phase earlier)
+//         phase 2  reads X1          issues W0 of tile t+2
+//         phase 3  (W0 kept in regs) issues W1 of tile t+2,  s_waitcnt vmcnt(X0+W0+W1 of t+2 stay in flight)
+//     i.e. two K-tile buffers (2 x 64 KiB at 256x256) and three half-tiles always in flight across the barriers;
+//     vmcnt is never drained inside the loop.
+//   * The two 4-wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same program one barrier apart,
+//     so on every SIMD one wave issues its 16 MFMAs while its partner does its fragment reads and DMA issue.
+//   * LDS image is lane-linear per DMA (8 rows x 128 B per wave-instruction); the bank swizzle
+//     chunk' = chunk ^ (row & 7) is applied to the per-lane SOURCE chunk and again on the ds_read_b128 fragment
+//     reads (conflict-free for the 16x16x32 operand: 16 rows x 4 k-chunks per instruction).
+//   * XCD-aware tile order, epilogue through LDS (full 512-byte row segments), rank extension as one extra MFMA
+//     k-step from registers.
+#include <type_traits>
+
+#include "vft_common.h"
+#include "linear8.h"
+
+// Diagnostic build only (tools/exp/lin8_probe.hip defines L8_STAMPS): cycle stamps of the first tiles of every
+// workgroup, written by one lane.  Never compiled into libvft_hip.so.
+#ifdef L8_STAMPS
+__device__ unsigned long long g_l8_stamps[512][8][12];
+#define L8_STAMP(i)                                                                              \
+    do {                                                                                         \
+        if (tid == 0 && stamp_it < 8) g_l8_stamps[blockIdx.x][stamp_it][i] = (unsigned long long)clock64(); \
+    } while (0)
+#else
+#define L8_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
+
+namespace {
+
+constexpr int NT = 512;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): the per-lane source is a 32-bit byte offset
+// (half the registers of a 64-bit pointer, no 64-bit address arithmetic per stage), the K advance rides in the scalar
+// offset, and a lane whose offset lies beyond the descriptor's extent delivers ZEROS — the convolution's padding.
+constexpr int OOB = (int)0x80000000u;  // beyond every extent this kernel accepts (< 2^31 bytes)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* l, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int BM_, int BN_, int WAVES_M_, bool CONV_>
+struct C8 {
+    static constexpr bool CONV = CONV_;
+    static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = 8 / WAVES_M_;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
+    static constexpr int FX = WM / 32, FW = WN / 32;            // 16-wide fragments per sub-tile (half of the wave tile)
+    static constexpr int XH = BM / 2 * 128, WH = BN / 2 * 128;  // bytes per half-tile (rows x 64 bf16)
+    static constexpr int TILE = 2 * XH + 2 * WH;                // one K-tile
+    static constexpr int DX = BM / 128, DW = BN / 128;          // DMA instructions per wave per half-tile
+    static constexpr int EP_ROWS = 64;                          // token rows per epilogue pass
+    static constexpr int EP_BYTES = EP_ROWS * BN * 2;           // epilogue image: its own region, so that the next
+                                                                // tile's DMAs can fly while this tile is written out
+    static constexpr size_t LDS_BYTES = 2 * (size_t)TILE + EP_BYTES;
+    static constexpr int WPS = LDS_BYTES <= 80 * 1024 ? 4 : 2;  // waves per SIMD the launch bound promises
+    static constexpr int SLOTS = (LDS_BYTES <= 80 * 1024 ? 2 : 1) * 256;  // resident workgroups on the chip
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && WM / 2 <= EP_ROWS, "wave tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
+    constexpr int BM = C::BM, BN = C::BN, FX = C::FX, FW = C::FW, XH = C::XH, WH = C::WH, TILE = C::TILE;
+    constexpr int DX = C::DX, DW = C::DW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm8[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv / C::WAVES_N, wc = wv % C::WAVES_N, grp = wv >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // ---- persistent workgroups: virtual tile ids vt = blockIdx.x, + gridDim.x, ...; the grid is a multiple of 8, so
+    //      vt & 7 labels the XCD group of every tile a workgroup takes.  id -> tile: XCD-contiguous, then bands of <= 8
+    //      N-tiles walked M-major (the workgroups of one XCD share weight tiles and activation rows through its L2)
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    auto decode = [&](int vt, int& m0, int& n0) {
+        const int xcd = vt & 7, q = ntiles >> 3, rr = ntiles & 7;
+        const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vt >> 3);
+        const int GN = tiles_n < 8 ? tiles_n : 8;
+        const int band = lin / (GN * tiles_m);
+        const int nb = min(GN, tiles_n - band * GN);
+        const int within = lin - band * GN * tiles_m;
+        n0 = (band * GN + within % nb) * BN;
+        m0 = (within / nb) * BM;
+    };
+
+    // ---- LDS-DMA sources.  One instruction = 8 rows x 128 B: lane -> (row = lane>>3, slot = lane&7); the slot
+    //      holds source chunk slot ^ (row & 7) (row & 7 == lane>>3: instruction bases are multiples of 8 rows)
+    const int drow = lane >> 3, dch = (lane & 7) ^ (lane >> 3);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc((void*)p.ex, 0, p.M * p.r * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rew = __builtin_amdgcn_make_buffer_rsrc((void*)p.ew, 0, p.N * p.r * 2, 0x00020000);
+    int gx[2][DX], gw[2][DW];  // byte offsets of this lane's chunks at k = 0
+    unsigned vmask[2][DX];     // CONV: which of the 9 taps fall inside the image for this lane's pixel
+    // CONV: K index = tap * Cin + c; the X halves of one K-tile are issued at different times, so each keeps its own
+    // incrementally advanced (tap, channel offset)
+    int ctap[2] = {0, 0}, cc0[2] = {0, 0};
+    auto setup = [&](int m0, int n0) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int q = 0; q < DX; ++q) {
+                const int row = hh * (BM / 2) + (wv * DX + q) * 8 + drow;
+                const int pm = min(m0 + row, p.M - 1);
+                gx[hh][q] = (int)(((int64_t)pm * p.ldx + dch * 8) * 2);
+                vmask[hh][q] = 0;
+                if (C::CONV) {
+                    const int rem = pm % (p.cH * p.cW), oh = rem / p.cW, ow = rem - oh * p.cW;
+                    unsigned m = 0;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+                        if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW) m |= 1u << tap;
+                    }
+                    vmask[hh][q] = m;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < DW; ++q) {
+                const int row = hh * (BN / 2) + (wv * DW + q) * 8 + drow;
+                gw[hh][q] = (int)(((int64_t)min(n0 + row, p.N - 1) * p.ldw + dch * 8) * 2);
+            }
+            ctap[hh] = 0, cc0[hh] = 0;
+        }
+    };
+
+    auto stage_x = [&](int t, int buf, int hh) {
+        unsigned char* dst = sm8 + buf * TILE + hh * XH + wv * DX * 1024;
+        if (C::CONV) {
+            const int tap = ctap[hh];
+            const int off = (((tap / 3 - 1) * p.cW + (tap % 3 - 1)) * (int)p.ldx + cc0[hh]) * 2;
+#pragma unroll
+            for (int q = 0; q < DX; ++q) dma16(rx, dst + q * 1024, ((vmask[hh][q] >> tap) & 1u) ? gx[hh][q] + off : OOB, 0);
+            cc0[hh] += 64;
+            if (cc0[hh] == p.cC) {
+                cc0[hh] = 0;
+                ++ctap[hh];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < DX; ++q) dma16(rx, dst + q * 1024, gx[hh][q], t * 128);
+        }
+    };
+    auto stage_w = [&](int t, int buf, int hh) {
+        unsigned char* dst = sm8 + buf * TILE + 2 * XH + hh * WH + wv * DW * 1024;
+#pragma unroll
+        for (int q = 0; q < DW; ++q) dma16(rw, dst + q * 1024, gw[hh][q], t * 128);
+    };
+
+    // ---- fragment read offsets (bytes inside a half-tile): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 kk + lq;
+    //      row & 7 == lane & 7 (sub-tile bases are multiples of 16 rows)
+    const int sw = ((lq ^ (lane & 7)) << 4);
+    const int xl = (wr * (C::WM / 2) + l15) * 128 + sw;               // k-step 0; k-step 1 = ^ 64
+    const int wl = 2 * XH + (wc * (C::WN / 2) + l15) * 128 + sw;
+
+    f32x4 acc[2][FX][2][FW];
+    bf16x8 xf[FX][2], w0[FW][2], w1[FW][2];
+    auto read_x = [&](const unsigned char* tb, int hh) {
+#pragma unroll
+        for (int i = 0; i < FX; ++i) {
+            xf[i][0] = *reinterpret_cast<const bf16x8*>(tb + hh * XH + i * 2048 + xl);
+            xf[i][1] = *reinterpret_cast<const bf16x8*>(tb + hh * XH + i * 2048 + (xl ^ 64));
+        }
+    };
+    auto read_w = [&](const unsigned char* tb, int hh, bf16x8 (&wf)[FW][2]) {
+#pragma unroll
+        for (int j = 0; j < FW; ++j) {
+            wf[j][0] = *reinterpret_cast<const bf16x8*>(tb + hh * WH + j * 2048 + wl);
+            wf[j][1] = *reinterpret_cast<const bf16x8*>(tb + hh * WH + j * 2048 + (wl ^ 64));
+        }
+    };
+    auto mma = [&](f32x4 (&a)[FX][2][FW], int hw, const bf16x8 (&wf)[FW][2]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < FX; ++i)
+#pragma unroll
+                for (int j = 0; j < FW; ++j) a[i][hw][j] = mfma16(wf[j][kk], xf[i][kk], a[i][hw][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+    const int nkt = p.K / 64;
+    // One K-tile = four phases.  has1 / has2: tiles t+1 / t+2 exist (wave-uniform).
+    auto tile = [&](int t, auto BUFc, bool has1, bool has2) {
+        constexpr int BUF = decltype(BUFc)::value;
+        const unsigned char* tb = sm8 + BUF * TILE;
+        // ---- phase 0: quadrant (X0, W0); re-fills X1 of the other buffer (tile t+1) ----
+        read_x(tb, 0);
+        read_w(tb, 0, w0);
+        if (has1) stage_x(t + 1, BUF ^ 1, 1);
+        lgk0();  // X0's slot is re-filled in the next phase: its reads are done before this rendezvous
+        bar();
+        mma(acc[0], 0, w0);
+        bar();
+        // ---- phase 1: (X0, W1); re-fills X0 (tile t+2).  W1's slot is re-filled two phases later, so its reads may
+        //      complete behind the rendezvous ----
+        read_w(tb, 1, w1);
+        if (has2) stage_x(t + 2, BUF, 0);
+        bar();
+        lgk0();
+        mma(acc[0], 1, w1);
+        bar();
+        // ---- phase 2: (X1, W1); re-fills W0 ----
+        read_x(tb, 1);
+        if (has2) stage_w(t + 2, BUF, 0);
+        bar();
+        lgk0();
+        mma(acc[1], 1, w1);
+        bar();
+        // ---- phase 3: (X1, W0 from registers); re-fills W1; everything of tile t+1 has landed after the wait (X0, W0,
+        //      W1 of tile t+2 stay in flight) ----
+        if (has2) {
+            stage_w(t + 2, BUF, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        bar();
+        mma(acc[1], 0, w0);
+        bar();
+    };
+    // first K-tile complete; X0 / W0 / W1 of the second in flight (its X1 follows in phase 0)
+    auto prologue = [&]() {
+        stage_x(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_w(0, 0, 1);
+        stage_x(0, 0, 1);
+        if (nkt > 1) {
+            stage_x(1, 1, 0);
+            stage_w(1, 1, 0);
+            stage_w(1, 1, 1);
+        }
+    };
+
+    bf16_t* const ep = reinterpret_cast<bf16_t*>(sm8 + 2 * TILE);
+    // Rank extension (r in {4, 8, 16}): the tile's rows of ex [BM][r] and ew [BN][r] are copied densely into the
+    // epilogue region by LDS-DMA while that region is idle (issued before a tile's first K-stages, or behind the
+    // previous tile's last epilogue pass), so they cost no registers and no exposed latency; rows beyond M / N read
+    // zeros through the descriptor's bounds check.
+    constexpr int EXW = BM * 32;  // byte offset of the ew copy (ex copy: BM rows x at most 32 bytes)
+    static_assert(BM * 32 + BN * 32 <= C::EP_BYTES, "rank-extension staging must fit in the epilogue region");
+    auto ext_dma = [&](int m0, int n0) {
+        if (p.ex == nullptr) return;
+        const int rb = p.r * 2;
+        unsigned char* eb = sm8 + 2 * TILE;
+        if (wv < BM * rb / 1024) dma16(rex, eb + wv * 1024, m0 * rb + wv * 1024 + lane * 16, 0);
+        if (wv < BN * rb / 1024) dma16(rew, eb + EXW + wv * 1024, n0 * rb + wv * 1024 + lane * 16, 0);
+    };
+    constexpr int CH = BN / 8, EPQ = (C::EP_ROWS * CH) / NT;  // 16-byte chunks per image row; chunks per thread per pass
+    constexpr int HP = (BM / 2) / C::EP_ROWS;                 // passes per X half
+
+    int vt = blockIdx.x, m0, n0;
+    decode(vt, m0, n0);
+    setup(m0, n0);
+    ext_dma(m0, n0);
+    prologue();
+#ifdef L8_STAMPS
+    int stamp_it = 0;
+#endif
+    for (;;) {
+        L8_STAMP(0);
+        // the stores of the previous tile's epilogue are younger than these DMAs, so the count below (which assumes the
+        // youngest operations are the second K-tile's DMAs) can only wait for MORE than it needs
+        if (nkt > 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        bar();
+        if (grp == 1) bar();  // stagger the groups by one barrier
+        L8_STAMP(1);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < FX; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < FW; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[a][i][b][j][e] = 0.f;
+        {
+            int t = 0;
+            for (; t + 1 < nkt; t += 2) {
+                tile(t, std::integral_constant<int, 0>{}, true, t + 2 < nkt);
+                tile(t + 1, std::integral_constant<int, 1>{}, t + 2 < nkt, t + 3 < nkt);
+            }
+            if (t < nkt) tile(t, std::integral_constant<int, 0>{}, false, false);
+        }
+        if (grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
+        L8_STAMP(2);
+
+        // ---- the next tile's first DMAs fly while this tile is written out --------------------------------------
+        const int cm0 = m0, cn0 = n0;
+        const int vn = vt + gridDim.x;
+        const bool more = vn < ntiles;
+        if (more) {
+            decode(vn, m0, n0);
+            setup(m0, n0);
+                    prologue();
+        }
+
+        L8_STAMP(3);
+        // Lane-constant addresses of the tail (rank extension, epilogue) must not be hoisted out of the persistent loop:
+        // they would stay live across the main loop, which has no register to spare.  An opaque copy of the thread id
+        // per tile makes them loop-variant for the compiler.
+        int etid = tid;
+        asm volatile("" : "+v"(etid));
+        const int el15 = etid & 15, elq = (etid & 63) >> 4;
+
+        // ---- rank-r extension: one more MFMA k-step on the staged [rows][r] operands (k slot 8 lq + e <-> rank index;
+        //      slots >= r are zero) --------------------------------------------------------------------------------
+        if (p.ex != nullptr) {
+            const int rb = p.r * 2, valid = p.r - 8 * elq;
+            const unsigned char* eb = sm8 + 2 * TILE;
+            auto frag = [&](int byte_base, int row) {
+                const unsigned char* a = eb + byte_base + (valid > 0 ? row * rb + elq * 16 : 0);
+                u32x2 lo = *reinterpret_cast<const u32x2*>(a), hi = *reinterpret_cast<const u32x2*>(a + 8);
+                if (valid < 4) lo = u32x2{0u, 0u};
+                if (valid < 8) hi = u32x2{0u, 0u};
+                const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                return __builtin_bit_cast(bf16x8, v);
+            };
+            bf16x8 ew[2][FW], ex[2][FX];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < FW; ++j) ew[b][j] = frag(EXW, b * (BN / 2) + wc * (C::WN / 2) + j * 16 + el15);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < FX; ++i) ex[a][i] = frag(0, a * (BM / 2) + wr * (C::WM / 2) + i * 16 + el15);
+            lgk0();
+            bar();  // every wave has its fragments: the region becomes the epilogue image
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < FX; ++i)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < FW; ++j) acc[a][i][b][j] = mfma16(ew[b][j], ex[a][i], acc[a][i][b][j]);
+        }
+
+        L8_STAMP(4);
+        // ---- epilogue: accumulators (+bias) -> bf16 image in LDS (64 token rows per pass; unpadded rows, 16-byte
+        //      chunk c of row r at chunk c ^ (r & 15): conflict-free 8-byte fragment writes and 16-byte row reads) ->
+        //      16-byte row-contiguous stores (+residual, loaded before the image is written) -----------------------
+        bf16x4 bv[2][FW];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < FW; ++j) {
+                const int fl = cn0 + b * (BN / 2) + wc * (C::WN / 2) + j * 16 + 4 * elq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[b][j][e] = (bf16_t)0.f;
+                if (p.bias != nullptr && fl < p.N) bv[b][j] = *reinterpret_cast<const bf16x4*>(p.bias + fl);
+            }
+#pragma unroll
+        for (int ps = 0; ps < BM / C::EP_ROWS; ++ps) {
+            const int a = ps / HP, sub = ps % HP;
+            const int mbase = cm0 + a * (BM / 2) + sub * C::EP_ROWS;
+            bf16x8 rv[EPQ];
+            if (p.res != nullptr) {
+#pragma unroll
+                for (int q = 0; q < EPQ; ++q) {
+                    const int idx = etid + NT * q, row = idx / CH, ch = idx % CH;
+                    const int m = min(mbase + row, p.M - 1), n = min(cn0 + ch * 8, p.N - 8);
+                    rv[q] = *reinterpret_cast<const bf16x8*>(p.res + (int64_t)m * p.ldres + n);
+                }
+            }
+            if ((wr * (C::WM / 2)) / C::EP_ROWS == sub) {
+                const int r0 = (wr * (C::WM / 2)) % C::EP_ROWS;
+#pragma unroll
+                for (int i = 0; i < FX; ++i) {
+                    const int row = r0 + i * 16 + el15;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < FW; ++j) {
+                            bf16x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[a][i][b][j][e] + (float)bv[b][j][e]);
+                            const int col = b * (BN / 2) + wc * (C::WN / 2) + j * 16 + 4 * elq;
+                            *reinterpret_cast<bf16x4*>(ep + row * BN + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))) = v;
+                        }
+                }
+            }
+            lgk0();
+            bar();
+#pragma unroll
+            for (int q = 0; q < EPQ; ++q) {
+                const int idx = etid + NT * q, row = idx / CH, ch = idx % CH;
+                const int m = mbase + row, n = cn0 + ch * 8;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row * BN + ((ch ^ (row & 15)) << 3));
+                if (p.res != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rv[q][e]);
+                }
+                if (m < p.M && n < p.N) *reinterpret_cast<bf16x8*>(p.y + (int64_t)m * p.ldy + n) = v;
+            }
+            lgk0();
+            bar();  // the image is re-used by the next pass
+            L8_STAMP(5 + ps);
+        }
+#ifdef L8_STAMPS
+        ++stamp_it;
+#endif
+        if (!more) break;
+        ext_dma(m0, n0);  // behind the last pass's barrier: the region is idle again
+        vt = vn;
+    }
+}
+
+template <class C>
+void launch8(const Lin8Params& p, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lin8_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::LDS_BYTES);
+        attr = true;
+    }
+    // persistent workgroups: one per resident slot (a multiple of 8, so that a workgroup stays in one XCD group), or
+    // one per tile when there are fewer tiles than slots
+    const unsigned tiles = (unsigned)(((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN));
+#ifdef L8_NONPERSIST
+    const unsigned grid = tiles;
+#else
+    const unsigned grid = tiles < (unsigned)C::SLOTS ? tiles : (unsigned)C::SLOTS;
+#endif
+    hipLaunchKernelGGL(lin8_kernel<C>, dim3(grid), dim3(NT), C::LDS_BYTES, st, p);
+}
+
+}  // namespace
+
+// cfg: 1 = 256x256, 2 = 256x128, 3 = 128x128 (see linear8.h)
+static int64_t x_extent(const Lin8Params& p, bool conv) {
+    return conv ? (int64_t)p.M * p.ldx * 2 : ((int64_t)(p.M - 1) * p.ldx + p.K) * 2;
+}
+static int64_t w_extent(const Lin8Params& p) { return ((int64_t)(p.N - 1) * p.ldw + p.K) * 2; }
+
+bool vft_lin8_fits(const Lin8Params& p, bool conv) {
+    const int64_t lim = (1LL << 31) - 4096;
+    return p.K % 64 == 0 && x_extent(p, conv) < lim && w_extent(p) < lim;
+}
+
+void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
+    p.x_bytes = (int)x_extent(p, conv);
+    p.w_bytes = (int)w_extent(p);
+    if (conv) {
+        if (cfg == 1) launch8<C8<256, 256, 2, true>>(p, st);
+        else if (cfg == 2) launch8<C8<256, 128, 4, true>>(p, st);
+        else launch8<C8<128, 128, 2, true>>(p, st);
+    } else {
+        if (cfg == 1) launch8<C8<256, 256, 2, false>>(p, st);
+        else if (cfg == 2) launch8<C8<256, 128, 4, false>>(p, st);
+        else launch8<C8<128, 128, 2, false>>(p, st);
+    }
+}
+
+// Which tile.  Workgroups are persistent, so a launch costs ceil(tiles / resident slots) rounds of one tile each; the
+// time of a round is the tile's area over the speed a slot sustains (measured relative to the 256x256 tile on MI355X:
+// 256x128 0.86 of a CU, 128x128 two slots per CU at 0.45 each — fewer MFMAs per fragment read).  The big tile wins
+// unless its last round is mostly empty (e.g. 320 tiles on 256 CUs) or N wastes most of its last tile column.
+int vft_lin8_pick(int M, int N, int K) {
+    (void)K;
+    const double speed[4] = {0.0, 1.0, 0.86, 0.45};
+    const int bm[4] = {0, 256, 256, 128}, bn[4] = {0, 256, 128, 128}, slots[4] = {0, 256, 256, 512};
+    int best = 1;
+    double best_t = 1e30;
+    for (int c = 1; c <= 3; ++c) {
+        const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
+        const long rounds = (tiles + slots[c] - 1) / slots[c];
+        const double t = (double)rounds * bm[c] * bn[c] / speed[c];
+        if (t < best_t * 0.97) best_t = t, best = c;  // ties and near-ties go to the larger tile
+    }
+    return best;
+}

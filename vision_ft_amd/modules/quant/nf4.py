@@ -99,8 +99,10 @@ class NF4Linear(nn.Linear):
     def _apply(self, fn, recurse=True):
         # keep the integer payload intact under .to(dtype): only move devices
         self._state = None
-        probe = fn(torch.zeros(1))
-        dev = probe.device
+        # probe on the payload's CURRENT device: a dtype-only conversion (.to(torch.bfloat16), .float()) then leaves
+        # the device alone instead of dragging the packed weight to the CPU next to a bias that stayed on the GPU
+        cur = self.weight.device
+        dev = cur if cur.type == "meta" else fn(torch.zeros(1, device=cur)).device
         self.weight = nn.Parameter(self.weight.data.to(dev), requires_grad=False)
         for name in ("absmax", "quant_map", "nested_absmax", "nested_quant_map"):
             t = getattr(self, name)

@@ -42,6 +42,18 @@ def get_scheduler(optimizer, scheduler_name: str, **kwargs):
     return cls(optimizer, **kwargs)
 
 
+def _accepts_capturable(optimizer_name: str) -> bool:
+    """True when the optimizer class takes `capturable=` (its step can then be captured into a HIP graph)."""
+    import inspect
+
+    module_name, class_name = optimizer_name.rsplit(".", 1) if "." in optimizer_name else ("torch.optim", optimizer_name)
+    try:
+        cls = getattr(importlib.import_module(module_name), class_name)
+        return "capturable" in inspect.signature(cls.__init__).parameters
+    except (ImportError, AttributeError, TypeError, ValueError):
+        return False
+
+
 def set_seed(seed: int) -> None:
     random.seed(seed)
     np.random.seed(seed)
@@ -124,11 +136,15 @@ class Trainer:
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.dp = DataParallelGrads(params)
         args = dict(self.config.optimizer.args)
-        if self.config.trainer.hip_graph and self.config.optimizer.name.endswith("AdamW") and torch.cuda.is_available():
+        if self.config.trainer.hip_graph and torch.cuda.is_available() and _accepts_capturable(self.config.optimizer.name):
             args.setdefault("capturable", True)
-            args.setdefault("fused", True)
+            if self.config.optimizer.name.rsplit(".", 1)[-1] in ("Adam", "AdamW", "SGD", "Adagrad"):
+                args.setdefault("fused", True)
             # a device-resident learning rate: LR schedulers then reach the captured optimizer kernel
             args["lr"] = torch.tensor(float(args["lr"]), dtype=torch.float32, device=params[0].device)
+        elif self.config.trainer.hip_graph and torch.cuda.is_available():
+            self.print(f"optimizer {self.config.optimizer.name} has no capturable mode: forward/backward replay from HIP "
+                       "graphs, the optimizer step runs eagerly")
         self.optimizer = get_optimizer(self.config.optimizer.name, params, **args)
         sc = self.config.scheduler
         self.scheduler = get_scheduler(self.optimizer, sc.name, **sc.args) if sc is not None else None
@@ -150,15 +166,19 @@ class Trainer:
         self.prepare_model()
         self.prepare_optimizer()
 
-    def backward(self, loss: torch.Tensor) -> None:
+    def backward(self, loss: torch.Tensor, current_step: int | None = None) -> None:
+        """reference :355-359.  There DDP all-reduces inside `accelerator.backward` on boundary micro-steps, so
+        `after_backward` (gradient clipping) sees the AVERAGED gradient on boundaries and the local one under
+        `no_sync`; the same order here: exchange first on boundaries, then clip."""
         self.raw_model.before_backward()
         (loss / self.gradient_accumulation_steps).backward()
+        if current_step is not None and current_step % self.gradient_accumulation_steps == 0:
+            self.dp.reduce_async()  # skipped on non-boundary micro-steps == the reference's no_sync (:301-308)
+            self.dp.wait()
         self.raw_model.after_backward()
 
     def apply_gradients(self, current_step: int) -> None:
         if current_step % self.gradient_accumulation_steps == 0:
-            self.dp.reduce_async()  # skipped on non-boundary micro-steps == the reference's no_sync (:301-308)
-            self.dp.wait()
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
@@ -203,7 +223,7 @@ class Trainer:
                         self.scheduler.step()
                 else:
                     loss = self.model(batch)
-                    self.backward(loss)
+                    self.backward(loss, step)
                     self.apply_gradients(step)
                 if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
                     self.losses.append(float(loss.detach()))

@@ -113,6 +113,12 @@ class DataParallelGrads:
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> list[int]:
-    """Rank r takes items r, r+W, r+2W, ... (what accelerate's prepare_data_loader does for the
-    reference's batch-per-item bucket loader, src/trainer/common.py:121)."""
-    return list(range(rank, n_items, world))
+    """Rank r takes items r, r+W, r+2W, ... and EVERY rank takes ceil(n/W) of them: when W does not divide n the last
+    round wraps around to the first items — what accelerate's prepare_data_loader (even_batches=True, its default)
+    does for the reference's batch-per-item bucket loader (src/trainer/common.py:121).  Equal step counts per rank are
+    what keeps the collectives matched: with unequal shards the longer ranks would issue a gradient all-reduce while
+    the shorter ones sit in the end-of-epoch barrier."""
+    if n_items <= 0:
+        return []
+    per_rank = -(-n_items // world)
+    return [(rank + i * world) % n_items for i in range(per_rank)]

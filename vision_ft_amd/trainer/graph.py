@@ -60,14 +60,35 @@ class GraphedOptimizerStep:
         self.graph.replay()
 
 
+class EagerOptimizerStep:
+    """Stand-in for `GraphedOptimizerStep` when the optimizer cannot be captured (no `capturable` mode: host-side
+    step counters / learning rates would be baked into the graph): forward + backward still replay from a graph,
+    the optimizer runs eagerly on accumulation boundaries."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer, dp: DataParallelGrads):
+        self.optimizer, self.dp = optimizer, dp
+
+    def replay(self) -> None:
+        self.optimizer.step()
+        self.dp.zero_grad()
+
+
+def optimizer_is_capturable(optimizer: torch.optim.Optimizer) -> bool:
+    return all(bool(g.get("capturable", False)) for g in optimizer.param_groups)
+
+
 class GraphedTrainStep:
     """One bucket shape's training step as HIP graphs.
 
     split=False (single GPU, no accumulation): forward + backward + optimizer in one graph.
     split=True  (DP or gradient accumulation): graph A = forward + backward (gradients accumulate in the flat
-    buffer); the optimizer graph (`opt_graph`, shared between bucket shapes) is replayed only on accumulation
-    boundaries, after the all-reduce.  `pool` lets all bucket graphs share one private memory pool — they
-    never replay concurrently, so the activation memory is paid once, not once per bucket."""
+    buffer); `after_backward` (gradient clipping) is its own small graph C, replayed after A on non-boundary
+    micro-steps (local gradients, the reference under `no_sync`) and AFTER the all-reduce on boundaries — the
+    reference clips the averaged gradient there (DDP reduces inside backward, src/trainer/common.py:355-359);
+    the optimizer graph B (`opt_graph`, shared between bucket shapes) is replayed only on boundaries.
+    `pool` lets all bucket graphs share one private memory pool — they never replay concurrently, so the
+    activation memory is paid once, not once per bucket.  An optimizer without a capturable mode runs eagerly
+    in place of graph B."""
 
     def __init__(self, forward_loss: Callable[[], torch.Tensor], optimizer: torch.optim.Optimizer,
                  dp: DataParallelGrads, warmup: int = 3, after_backward: Callable[[], None] | None = None,
@@ -78,7 +99,8 @@ class GraphedTrainStep:
         self.dp = dp
         self.after_backward = after_backward
         self.loss_scale = float(loss_scale)  # 1 / gradient_accumulation_steps; the reported loss stays unscaled
-        self.single = dp.world == 1 and not split
+        self.capturable = optimizer_is_capturable(optimizer)
+        self.single = dp.world == 1 and not split and self.capturable
         self.loss: torch.Tensor | None = None
         self._eager(warmup)  # allocator, MIOpen find, lazy kernel attributes: everything un-capturable happens here
         self._capture(pool, opt_graph)
@@ -111,16 +133,24 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph_a, pool=pool):
             loss = self.forward_loss()
             (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
-            if self.after_backward is not None:
-                self.after_backward()
             if self.single:
+                if self.after_backward is not None:
+                    self.after_backward()
                 self.optimizer.step()
                 self.dp.zero_grad()
             self.loss = loss.detach()
-        self.graph_b = None
+        self.graph_b = self.graph_c = None
         if not self.single:
-            self.graph_b = opt_graph if opt_graph is not None else GraphedOptimizerStep(self.optimizer, self.dp,
-                                                                                       pool=self.graph_a.pool())
+            if self.after_backward is not None:
+                self.graph_c = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_c, pool=self.graph_a.pool()):
+                    self.after_backward()
+            if opt_graph is not None:
+                self.graph_b = opt_graph
+            elif self.capturable:
+                self.graph_b = GraphedOptimizerStep(self.optimizer, self.dp, pool=self.graph_a.pool())
+            else:
+                self.graph_b = EagerOptimizerStep(self.optimizer, self.dp)
 
     def pool(self):
         return self.graph_a.pool()
@@ -129,8 +159,26 @@ class GraphedTrainStep:
         """One micro-step (forward + backward); on an accumulation boundary also the gradient exchange and the
         optimizer step.  Returns the (device-resident, static) loss tensor of this micro-step."""
         self.graph_a.replay()
-        if self.graph_b is not None and boundary:
-            self.dp.reduce_async()
-            self.dp.wait()
-            self.graph_b.replay()
+        if self.graph_b is None:
+            return self.loss
+        if boundary:
+            self.dp.reduce_async()  # side stream; whatever the host queues before finish() overlaps with it
+            self._open = True
+            if not self.defer_finish:
+                self.finish()
+        elif self.graph_c is not None:
+            self.graph_c.replay()
         return self.loss
+
+    defer_finish = False  # True: the caller runs finish() itself (after staging the next batch, logging, ...)
+    _open = False
+
+    def finish(self) -> None:
+        """Second half of a boundary step: wait for the gradient exchange, clip the averaged gradient, update."""
+        if not self._open:
+            return
+        self._open = False
+        self.dp.wait()
+        if self.graph_c is not None:
+            self.graph_c.replay()
+        self.graph_b.replay()
