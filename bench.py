@@ -123,6 +123,21 @@ def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int
     return fwd
 
 
+def physical_cores() -> int:
+    """Physical host cores available to this process (the CPU leg uses all of them)."""
+    try:
+        import psutil
+
+        n = psutil.cpu_count(logical=False) or 0
+    except Exception:
+        n = 0
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(n or avail, avail))
+
+
 def cpu_baseline(threads: int) -> dict:
     from oracle.bench_cpu import time_sdxl_lora_step
     from vision_ft_amd.models.sdxl import Denoiser, DenoiserConfig
@@ -133,10 +148,10 @@ def cpu_baseline(threads: int) -> dict:
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     linears = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.Linear)]
     targets = sorted(set(get_target_keys(["attn1", "attn2", ".ff."], [], [n for n, _ in m.named_modules()])) & set(linears))
-    r = time_sdxl_lora_step(shapes, targets, threads=threads, warmup=1, steps=2)
+    r = time_sdxl_lora_step(shapes, targets, threads=threads, warmup=2, steps=5)
     return {"value": round(r["images_per_s"], 5), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"oracle restatement of BASELINE config 1 (SDXL UNet LoRA r4 x{len(targets)} Linears, B=1, 512^2, AdamW, "
-                      f"autocast cpu bf16): 1 warm-up + 2 timed steps, {r['s_per_step']:.2f} s/step"}
+                      f"autocast cpu bf16) on all {threads} physical host cores: 2 warm-up + 5 timed steps, {r['s_per_step']:.2f} s/step"}
 
 
 def per_call_roofline(prof: dict) -> dict:
@@ -156,20 +171,52 @@ def per_call_roofline(prof: dict) -> dict:
     return out
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.csv:
-    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py, gfx950 x2 fetch
-    correction applied) — measured at the kernel's dominant bench shape, not inside this run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.csv")
-    try:
-        import csv
+# hand-written kernels by family: (profile-key prefixes, HIP kernel name, roofline that bounds it)
+FAMILIES = {
+    "linear_gemm": (("linear_fwd",), "lin8_kernel (vft_linear_fwd: base GEMM + bias + LoRA rank extension + skip, forward and data gradient)", "mfma"),
+    "attention_bwd": (("attn_bwd",), "attn_bwd_dkdv_kernel + attn_bwd_dq_kernel", "mfma"),
+    "attention_fwd": (("attn_fwd",), "attn_fwd_kernel", "mfma"),
+    "conv3x3": (("conv3x3",), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
+    "gemm_nf4": (("gemm_nf4",), "linear_kernel NF4 modes (vft_linear_nf4)", "mfma"),
+    "lora_rank": (("lora_",), "lora_rows_kernel / lora_wgrad kernels", "hbm"),
+    "norms_activations": (("norm_", "groupnorm_", "geglu_", "swiglu_", "gate_residual", "qk_norm_rope"), "norm / GroupNorm / GEGLU / SwiGLU kernels", "hbm"),
+}
 
-        for row in csv.DictReader(open(path)):
-            if row["kernel"] == kernel:
-                return (round(float(row["traffic_MB"]) * 1e6),
-                        f"bytes/launch at B24 H10 S4096 D64 (the 64x64-latent self-attention); algorithmic {row['algorithmic_MB']} MB")
-    except OSError:
-        pass
+
+def family_table(prof: dict, steps: int) -> dict:
+    out = {}
+    for fam, (prefixes, kname, bound) in FAMILIES.items():
+        keys = [k for k in prof if k.startswith(prefixes)]
+        ms = sum(prof[k]["ms"] for k in keys)
+        if ms <= 0:
+            continue
+        work = sum(prof[k]["work"] for k in keys)
+        n = sum(prof[k]["launches"] for k in keys)
+        rate = work / (ms * 1e-3)
+        peak = PEAK_BF16_MFMA_TFLOPS * 1e12 if bound == "mfma" else PEAK_HBM_GBS * 1e9
+        out[fam] = {"kernel": kname, "bound": bound, "ms_per_step": round(ms / steps, 2), "launches_per_step": n // max(steps, 1),
+                    "achieved": round(rate / (1e12 if bound == "mfma" else 1e9), 1), "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                    "frac": round(rate / peak, 4), "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                    "work_per_launch": round(work / max(n, 1) / 1e9, 3)}
+    return out
+
+
+def pmc_traffic(family: str):
+    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r02_pmc_hbm_traffic.csv, falling
+    back to round 1's file: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py,
+    gfx950 x2 fetch correction applied) — measured at the shape named in the note, not inside this run."""
+    import csv
+
+    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkdv_kernel"}.get(family)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+        try:
+            for row in csv.DictReader(open(os.path.join(root, name))):
+                if want and row["kernel"] == want:
+                    return (round(float(row["traffic_MB"]) * 1e6),
+                            f"{name}: bytes/launch at {row.get('shape', 'the headline shape of tools/pmc_run.py')}; algorithmic {row['algorithmic_MB']} MB")
+        except OSError:
+            pass
     return None, None
 
 
@@ -181,6 +228,7 @@ def main():
     ap.add_argument("--workload", default="sdxl_lora", choices=list(F_ALG))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single", action="store_true", help="time only --workload (a default run adds an AuraFlow-LoRA leg)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-gemm-table", action="store_true", help="library GEMMs use their default heuristic, not the committed table")
     ap.add_argument("--tune-gemms", action="store_true", help="time library GEMM solutions for missing shapes and update the table")
@@ -207,137 +255,173 @@ def main():
     from vision_ft_amd.trainer.dp import DataParallelGrads
 
     gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
-
-    batch = args.batch or {"sdxl_lora": 24, "sdxl_full": 16, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4,
-                           "sdxl_buckets": 8}[args.workload]
-    model = build(args.workload, device)
-    params = [p for p in model.parameters() if p.requires_grad]
-    dp = DataParallelGrads(params)
-    use_graph = not args.no_graph and not args.workload.startswith("lumina")  # Lumina2's ragged assembly reads lengths on the host
-    opt = torch.optim.AdamW(params, lr=1e-3, fused=True, capturable=use_graph)
-    fwd = make_step(args.workload, model, device, batch, seed=42 + rank)
-
-    def eager_step():
-        loss = fwd()
-        loss.backward()
-        dp.reduce_async()
-        dp.wait()
-        opt.step()
-        dp.zero_grad()
-        return loss
-
-    imgs_per_step = batch
-    bucket_note = None
-    if args.workload == "sdxl_buckets":
-        # BASELINE config 5: mixed aspect-ratio buckets {640x1536 ... 1536x640}, one bucket per micro-batch drawn
-        # per rank from a seeded uniform multinomial, 4 micro-batches accumulated per optimizer step.  One
-        # forward/backward graph per bucket shape (shared memory pool), one shared optimizer graph.
-        from vision_ft_amd.dataset.synthetic import headline_buckets
-        from vision_ft_amd.trainer.graph import GraphedTrainStep
-
-        ga = 4
-        buckets = headline_buckets()
-        fwds = [make_step(args.workload, model, device, batch, seed=42 + rank, wh=wh) for wh in buckets]
-        graphs, opt_graph, pool = [], None, None
-        for f in fwds:
-            g_ = GraphedTrainStep(f, opt, dp, warmup=1, split=True, opt_graph=opt_graph, pool=pool, loss_scale=1.0 / ga)
-            opt_graph, pool = g_.graph_b, g_.pool()
-            graphs.append(g_)
-        draw = torch.Generator().manual_seed(1234 + rank)
-        counts = [0] * len(buckets)
-
-        def step():
-            for m in range(ga):
-                b = int(torch.randint(len(buckets), (1,), generator=draw))
-                counts[b] += 1
-                loss_ = graphs[b](boundary=m == ga - 1)
-            return loss_
-
-        imgs_per_step = batch * ga
-        bucket_note = {"buckets_wh": buckets, "grad_accum": ga, "draws": counts}
-        fwd = fwds[buckets.index((1024, 1024))]
-    elif use_graph:
-        from vision_ft_amd.trainer.graph import GraphedTrainStep
-
-        step = GraphedTrainStep(fwd, opt, dp, warmup=2)
-    else:
-        step = eager_step
+    default_batch = {"sdxl_lora": 24, "sdxl_full": 16, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4, "sdxl_buckets": 8}
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    kernels.set_profiling(rank == 0 and not use_graph)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof_steps = args.steps
-    peak_timed = torch.cuda.max_memory_allocated(device) / 2**30
-    if use_graph:
-        # release the graphs' private pool before the eager timing pass allocates its own activations
-        step = None
-        if args.workload == "sdxl_buckets":
+    def run_workload(workload: str, batch: int, steps: int, warmup: int) -> dict:
+        """Build, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then an eager pass with
+        HIP events around every hand-written launch.  Returns the result dict of this workload."""
+        model = build(workload, device)
+        params = [p for p in model.parameters() if p.requires_grad]
+        dp = DataParallelGrads(params)
+        use_graph = not args.no_graph and not workload.startswith("lumina")  # Lumina2's ragged assembly reads lengths on the host
+        opt = torch.optim.AdamW(params, lr=1e-3, fused=True, capturable=use_graph)
+        fwd = make_step(workload, model, device, batch, seed=42 + rank)
+
+        def eager_step():
+            loss = fwd()
+            loss.backward()
+            dp.reduce_async()
+            dp.wait()
+            opt.step()
+            dp.zero_grad()
+            return loss
+
+        imgs_per_step = batch
+        bucket_note = None
+        graphs = []
+        if workload == "sdxl_buckets":
+            # BASELINE config 5: mixed aspect-ratio buckets {640x1536 ... 1536x640}, one bucket per micro-batch drawn
+            # per rank from a seeded uniform multinomial, 4 micro-batches accumulated per optimizer step.  One
+            # forward/backward graph per bucket shape (shared memory pool), one shared optimizer graph.
+            from vision_ft_amd.dataset.synthetic import headline_buckets
+            from vision_ft_amd.trainer.graph import GraphedTrainStep
+
+            ga = 4
+            buckets = headline_buckets()
+            fwds = [make_step(workload, model, device, batch, seed=42 + rank, wh=wh) for wh in buckets]
+            opt_graph, pool = None, None
+            for f in fwds:
+                g_ = GraphedTrainStep(f, opt, dp, warmup=1, split=True, opt_graph=opt_graph, pool=pool, loss_scale=1.0 / ga)
+                opt_graph, pool = g_.graph_b, g_.pool()
+                graphs.append(g_)
+            draw = torch.Generator().manual_seed(1234 + rank)
+            counts = [0] * len(buckets)
+
+            def step():
+                for m in range(ga):
+                    b = int(torch.randint(len(buckets), (1,), generator=draw))
+                    counts[b] += 1
+                    loss_ = graphs[b](boundary=m == ga - 1)
+                return loss_
+
+            imgs_per_step = batch * ga
+            bucket_note = {"buckets_wh": buckets, "grad_accum": ga, "draws": counts}
+            fwd = fwds[buckets.index((1024, 1024))]
+        elif use_graph:
+            from vision_ft_amd.trainer.graph import GraphedTrainStep
+
+            step = GraphedTrainStep(fwd, opt, dp, warmup=2)
+        else:
+            step = eager_step
+
+        for _ in range(warmup):
+            step()
+        kernels.set_profiling(rank == 0 and not use_graph)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof_steps = steps
+        peak_timed = torch.cuda.max_memory_allocated(device) / 2**30
+        eager_ms = None
+        if use_graph:
+            # release the graphs' private pool before the eager timing pass allocates its own activations
+            step = None
             graphs.clear()
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            # per-kernel HIP-event timing cannot be recorded inside a graph replay: time the same step
+            # eagerly (same process, same tensors) right after the timed region, outside of it.  Every rank
+            # runs it (the step contains the gradient all-reduce); only rank 0 records.
+            prof_steps = 2
+            kernels.set_profiling(rank == 0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(prof_steps):
+                eager_step()
+            e1.record()
+            torch.cuda.synchronize()
+            eager_ms = e0.elapsed_time(e1) / prof_steps
+        prof = kernels.profile_report() if rank == 0 else {}
+        kernels.set_profiling(False)
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        res = {}
+        if rank == 0:
+            images_s = world * imgs_per_step * steps / elapsed
+            ms_per_step = 1e3 * elapsed / steps
+            fam = family_table(prof, prof_steps)
+            ours_ms = sum(v["ms_per_step"] for v in fam.values())
+            # the kernel with the largest share of the step among the hand-written ones (measured, not assumed)
+            dom = max(fam, key=lambda k: fam[k]["ms_per_step"]) if fam else None
+            traffic, traffic_note = pmc_traffic(dom) if dom else (None, None)
+            roofline = {"bound": fam[dom]["bound"], "kernel": fam[dom]["kernel"], "family": dom, "achieved": fam[dom]["achieved"],
+                        "peak": PEAK_BF16_MFMA_TFLOPS if fam[dom]["bound"] == "mfma" else PEAK_HBM_GBS, "unit": fam[dom]["unit"],
+                        "frac": fam[dom]["frac"], "traffic": traffic, "traffic_note": traffic_note,
+                        "avg_launch_us": fam[dom]["avg_launch_us"], "launches_per_step": fam[dom]["launches_per_step"],
+                        "share_of_step": round(fam[dom]["ms_per_step"] / ms_per_step, 3)} if dom else {}
+            roofline.update({
+                "families": fam,
+                "hand_written_ms_per_step": round(ours_ms, 1),
+                # what is NOT one of our C-ABI launches in the eager pass: library GEMMs / MIOpen convolutions that remain
+                # (time-embedding MLPs, 4-channel stem/head, stride-2 and 1x1 convolutions, weight gradients of a full
+                # fine-tune), ATen elementwise, the optimizer
+                "library_and_aten_ms_per_step": round(max(ms_per_step - ours_ms, 0.0), 1),
+                "eager_pass_ms_per_step": None if eager_ms is None else round(eager_ms, 1),
+                "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
+                "per_call": per_call_roofline(prof),
+                "measured": "HIP events around each launch, " + ("eager pass after the graph-replayed timed region" if use_graph else "inside the timed region"),
+                "step_mfma_frac": round(images_s / world * F_ALG[workload] / PEAK_BF16_MFMA_TFLOPS, 4)})
+            res = {
+                "value": round(images_s, 3), "ms_per_step": round(ms_per_step, 2),
+                "config": {"workload": workload, "resolution": "mixed buckets ~1 MP" if bucket_note else "1024x1024", "per_gpu_batch": batch,
+                           "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph,
+                           "gemm_table": bool(gemm_table), "lora_in_gemm": bool(kernels.FUSED_LORA_GEMM),
+                           "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5),
+                           "peak_mem_gib": round(peak_timed, 1), "algorithmic_tflop_per_image": F_ALG[workload],
+                           **({"buckets": bucket_note} if bucket_note else {}),
+                           **({"base_weights": "NF4 (blocksize 64, double-quantised absmax), dequantised in the GEMM kernel"}
+                              if workload == "lumina_qlora" else {})},
+                "roofline": roofline,
+            }
+        # free everything before the next leg
+        del model, params, dp, opt, fwd
         import gc
 
         gc.collect()
         torch.cuda.empty_cache()
-    if use_graph:
-        # per-kernel HIP-event timing cannot be recorded inside a graph replay: time the same step
-        # eagerly (same process, same tensors) right after the timed region, outside of it.  Every rank
-        # runs it (the step contains the gradient all-reduce); only rank 0 records.
-        prof_steps = 2
-        kernels.set_profiling(rank == 0)
-        for _ in range(prof_steps):
-            eager_step()
-        torch.cuda.synchronize()
-    prof = kernels.profile_report() if rank == 0 else {}
-    kernels.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        torch.cuda.reset_peak_memory_stats(device)
+        return res
+
+    main_res = run_workload(args.workload, args.batch or default_batch[args.workload], args.steps, args.warmup)
+    # The metric names two models ("SDXL-LoRA, AuraFlow-MMDiT"): a default run also times AuraFlow-LoRA (BASELINE config 3,
+    # rank 16, 252 Linears) with its own roofline, reported under "workloads".  `value` stays the named workload's.
+    legs = {}
+    if args.workload == "sdxl_lora" and not args.single:
+        legs["aura_lora"] = run_workload("aura_lora", default_batch["aura_lora"], max(3, min(args.steps, 5)), 2)
 
     if rank == 0:
-        images_s = world * imgs_per_step * args.steps / elapsed
-        # roofline of the dominant hand-written kernel (attention forward): ALGORITHMIC flops / measured time
-        fwd_keys = [k for k in prof if k.startswith("attn_fwd")]
-        work = sum(prof[k]["work"] for k in fwd_keys)
-        ms = sum(prof[k]["ms"] for k in fwd_keys)
-        ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        n_launch = sum(prof[k]["launches"] for k in fwd_keys)
-        traffic, traffic_note = pmc_traffic("attn_fwd_kernel") if args.workload.startswith("sdxl") else (None, None)
-        roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": traffic_note,
-                    "avg_launch_us": round(1e3 * ms / max(n_launch, 1), 2),
-                    "gflop_per_launch": round(work / max(n_launch, 1) / 1e9, 2),
-                    "launches_per_step": n_launch // max(prof_steps, 1),
-                    "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
-                    "per_call": per_call_roofline(prof),
-                    "measured": "HIP events around each launch, " + ("eager pass after the graph-replayed timed region" if use_graph else "inside the timed region"),
-                    "step_mfma_frac": round(images_s / world * F_ALG[args.workload] / PEAK_BF16_MFMA_TFLOPS, 4)}
         out = {
-            "metric": "train images/sec at 1024^2", "value": round(images_s, 3), "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "metric": "train images/sec at 1024^2", "value": main_res["value"], "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": args.workload, "resolution": "mixed buckets ~1 MP" if bucket_note else "1024x1024", "per_gpu_batch": batch,
-                       "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph, "gemm_table": bool(gemm_table),
-                       "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5),
-                       "peak_mem_gib": round(peak_timed, 1),
-                       **({"buckets": bucket_note} if bucket_note else {}),
-                       **({"base_weights": "NF4 (blocksize 64, double-quantised absmax), dequantised in the GEMM kernel"}
-                          if args.workload == "lumina_qlora" else {})},
-            "roofline": roofline,
+            "config": main_res["config"], "roofline": main_res["roofline"],
         }
+        if legs:
+            out["workloads"] = {k: {"metric": "train images/sec at 1024^2", "unit": "images/s", **v} for k, v in legs.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(threads=min(os.cpu_count() or 1, 16))
+            out["cpu_baseline"] = cpu_baseline(threads=physical_cores())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

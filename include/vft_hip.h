@@ -89,10 +89,11 @@ int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
 int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora_up, void* t_out,
                  void* up_t_out, const void* residual, int M, int K, int N, int r, int64_t ldx,
                  int64_t ldy, int64_t ldres, float scale, void* stream);
-/* t[M][r] = x . lora_down^T only: the adapter's low-rank activations, for consumers that apply the update
- * themselves (vft_geglu_lora_*, the rank extension of vft_linear_fwd / vft_linear_nf4). */
+/* t[M][r] = scale * (x . lora_down^T) only: the adapter's low-rank activations, for consumers that apply the update
+ * themselves (vft_geglu_lora_*, the rank extension of vft_linear_fwd / vft_linear_nf4); scale = alpha / rank lets the
+ * consumer use lora_up as stored (peft/lora.py:92-104), scale = 1 gives the plain activations. */
 int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
-                  void* stream);
+                  float scale, void* stream);
 int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
                     int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream);
 size_t vft_lora_wgrad_workspace(int M, int K, int N, int r);
@@ -203,8 +204,9 @@ int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void* bias, int
  * One launch for the reference's LoRALinear.forward (peft/lora.py:92-104: linear(x) + lora_up(lora_down(x)) * s):
  * ext_x = lora_down(x) (vft_lora_down), ext_w = s * lora_up; and for the `x + attn(x)` / `x + ff(x)` residual
  * adds of the transformer blocks (sdxl/denoiser.py:273-284).  The data gradient dx = dy.W + (dy.B).(sA) is the
- * same call on the transposed weight.  K % 64 == 0, N % 8 == 0, strides % 8 == 0, 16-byte aligned pointers;
- * r in {4, 8, 16, 32} when the rank extension is present (ext_x / ext_w dense [.,r]).
+ * same call on the transposed weight.  K % 32 == 0, N % 8 == 0, strides % 8 == 0, 16-byte aligned pointers;
+ * r in {4, 8, 16, 32} when the rank extension is present (ext_x / ext_w dense [.,r]).  K % 64 == 0 with r <= 16 and
+ * operands below 2 GiB run on the second-generation kernel (csrc/linear8.hip), everything else on the first.
  */
 int vft_linear_fwd(const void* x, const void* w, void* y, const void* bias, const void* residual,
                    const void* ext_x, const void* ext_w, int M, int N, int K, int r, int64_t ldx,

@@ -455,6 +455,109 @@ def gen_samplers():
 
 
 # ----------------------------------------------------------------------------------------------
+def gen_checkpoint_keys():
+    """Checkpoint key renaming of the three pipelines (src/models/sdxl/util.py, lumina2/util.py, auraflow/pipeline.py:35-54):
+    original single-file names <-> module-tree names, VAE / text-encoder prefixes included, and the ComfyUI adapter names.
+    The original-side key lists below are data (names found in sgm / ComfyUI checkpoints, the ones the reference's
+    tests/models/test_sdxl.py:21-151 uses plus a few per family); every expected value comes from the reference."""
+    import importlib.util
+
+    def by_path(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    su = by_path("_ref_sdxl_util", "src/models/sdxl/util.py")
+    lu = by_path("_ref_lumina_util", "src/models/lumina2/util.py")
+    sdxl_orig = [
+        "model.diffusion_model.input_blocks.5.1.transformer_blocks.1.attn1.to_out.0.weight",
+        "model.diffusion_model.input_blocks.3.0.op.bias",
+        "model.diffusion_model.input_blocks.0.0.weight",
+        "model.diffusion_model.output_blocks.7.0.in_layers.0.weight",
+        "model.diffusion_model.output_blocks.8.0.skip_connection.weight",
+        "model.diffusion_model.output_blocks.2.2.conv.weight",
+        "model.diffusion_model.middle_block.1.transformer_blocks.0.attn1.to_k.weight",
+        "model.diffusion_model.middle_block.0.emb_layers.1.bias",
+        "model.diffusion_model.time_embed.0.weight",
+        "model.diffusion_model.label_emb.0.2.bias",
+        "model.diffusion_model.out.2.weight",
+        "diffusion_model.input_blocks.4.1.proj_in.weight",
+        "conditioner.embedders.0.transformer.text_model.embeddings.position_embedding.weight",
+        "conditioner.embedders.1.model.transformer.resblocks.0.attn.in_proj_bias",
+        "conditioner.embedders.1.model.text_projection",
+        "first_stage_model.encoder.down.1.block.0.conv1.weight",
+        "first_stage_model.encoder.down.2.block.0.nin_shortcut.weight",
+        "first_stage_model.encoder.down.0.downsample.conv.weight",
+        "first_stage_model.decoder.mid.attn_1.q.weight",
+        "first_stage_model.decoder.mid.attn_1.proj_out.bias",
+        "first_stage_model.decoder.mid.block_2.norm1.weight",
+        "first_stage_model.decoder.up.0.block.0.nin_shortcut.weight",
+        "first_stage_model.decoder.up.3.upsample.conv.weight",
+        "first_stage_model.post_quant_conv",
+        "first_stage_model.encoder.norm_out.weight",
+        "first_stage_model.decoder.conv_in.weight",
+    ]
+    unet_orig = ["input_blocks.5.1.transformer_blocks.1.attn1.to_out.0.weight", "input_blocks.3.0.op.bias",
+                 "output_blocks.7.0.in_layers.0.weight", "output_blocks.8.0.skip_connection.weight",
+                 "middle_block.1.transformer_blocks.0.attn1.to_k.weight", "out.2.bias", "time_embed.2.weight"]
+    vae_orig = ["encoder.down.1.block.0.conv1.weight", "encoder.down.2.block.0.nin_shortcut.weight", "decoder.mid.attn_1.q.weight",
+                "decoder.mid.attn_1.k.bias", "decoder.mid.attn_1.norm.weight", "decoder.mid.block_1.conv2.bias",
+                "decoder.up.0.block.0.nin_shortcut.weight", "decoder.up.2.block.1.norm2.weight", "post_quant_conv",
+                "encoder.norm_out.weight", "decoder.conv_in.weight", "decoder.up.1.upsample.conv.bias",
+                "encoder.down.3.block.1.conv2.weight"]
+    J = {"sdxl": {
+        "from_original": [[k, su.convert_from_original_key(k)] for k in sdxl_orig],
+        "to_original": [[su.convert_from_original_key(k), su.convert_to_original_key(su.convert_from_original_key(k))] for k in sdxl_orig],
+        "unet_from_original": [[k, su.unet_block_convert_from_original_key(k)] for k in unet_orig],
+        "unet_to_original": [[su.unet_block_convert_from_original_key(k),
+                              su.unet_block_convert_to_original_key(su.unet_block_convert_from_original_key(k))] for k in unet_orig],
+        "vae_from_original": [[k, su.vae_convert_from_original_key(k)] for k in vae_orig],
+        "vae_to_original": [[su.vae_convert_from_original_key(k),
+                             su.vae_convert_to_original_key(su.vae_convert_from_original_key(k))] for k in vae_orig],
+        "comfy": [[k, su.convert_to_comfy_key(k)] for k in [su.convert_from_original_key(k) for k in sdxl_orig]],
+    }}
+    lumina_orig = ["model.diffusion_model.layers.3.attention.qkv.weight", "model.diffusion_model.noise_refiner.0.adaLN_modulation.1.bias",
+                   "model.diffusion_model.cap_embedder.1.weight", "diffusion_model.final_layer.linear.weight",
+                   "model.diffusion_model.layers.0.attention.qkv.weight.quant_state.bitsandbytes__nf4",
+                   "text_encoders.gemma2_2b.transformer.model.layers.0.mlp.up_proj.weight",
+                   "vae.decoder.mid.attn_1.q.weight", "vae.encoder.down.0.block.1.conv1.weight", "vae.decoder.up.1.upsample.conv.bias"]
+    J["lumina2"] = {
+        "from_original": [[k, lu.convert_from_original_key(k)] for k in lumina_orig],
+        "to_original": [[lu.convert_from_original_key(k), lu.convert_to_original_key(lu.convert_from_original_key(k))] for k in lumina_orig],
+        "comfy": [[k, lu.convert_to_comfy_key(k)] for k in [lu.convert_from_original_key(k) for k in lumina_orig]],
+    }
+    # AuraFlow's converters live in pipeline.py (which imports diffusers); they are three module-level functions over
+    # three prefix constants, evaluated here in a namespace that holds only those constants
+    src = open(os.path.join(REF, "src/models/auraflow/pipeline.py")).read()
+    import ast
+
+    tree = ast.parse(src)
+    ns = {"DENOISER_TENSOR_PREFIX": "model.", "VAE_TENSOR_PREFIX": "vae.",
+          "TEXT_ENCODER_TENSOR_PREFIX": "text_encoders.pile_t5xl.transformer."}
+    for const, rel in (("DENOISER_TENSOR_PREFIX", "src/models/auraflow/denoiser.py"), ("VAE_TENSOR_PREFIX", "src/models/auraflow/vae.py"),
+                       ("TEXT_ENCODER_TENSOR_PREFIX", "src/models/auraflow/text_encoder.py")):
+        for node in ast.parse(open(os.path.join(REF, rel)).read()).body:
+            if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == const:
+                assert ast.literal_eval(node.value) == ns[const], (const, ast.literal_eval(node.value))
+    funcs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in
+             ("convert_to_original_key", "convert_to_comfy_key", "convert_from_original_key")]
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), "auraflow_pipeline_converters", "exec"), ns)
+    aura_orig = ["model.double_layers.0.attn.w2q.weight", "model.single_layers.11.mlp.c_fc1.weight", "model.register_tokens",
+                 "model.t_embedder.mlp.0.weight", "diffusion_model.single_layers.3.modCX.1.weight", "model.final_linear.weight",
+                 "vae.decoder.conv_in.weight", "text_encoders.pile_t5xl.transformer.encoder.block.0.layer.0.SelfAttention.q.weight"]
+    J["auraflow"] = {
+        "from_original": [[k, ns["convert_from_original_key"](k)] for k in aura_orig],
+        "to_original": [[ns["convert_from_original_key"](k), ns["convert_to_original_key"](ns["convert_from_original_key"](k))] for k in aura_orig],
+        "comfy": [[k, ns["convert_to_comfy_key"](k)] for k in [ns["convert_from_original_key"](k) for k in aura_orig]],
+        "prefixes": {k: v for k, v in ns.items() if k.endswith("_PREFIX")},
+    }
+    with open(os.path.join(OUT, "checkpoint_keys.json"), "w") as f:
+        json.dump(J, f, indent=0)
+    print("checkpoint_keys:", {k: {kk: len(vv) for kk, vv in v.items()} for k, v in J.items()})
+
+
+# ----------------------------------------------------------------------------------------------
 def gen_index():
     import importlib.util
 
@@ -609,8 +712,8 @@ def gen_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     import_reference()
-    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "aura", "lumina", "samplers"]
+    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "aura", "lumina", "samplers", "checkpoint_keys"]
     torch.set_num_threads(8)
     for w in which:
         {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "sdxl_rect": gen_sdxl_rect, "aura": gen_aura, "lumina": gen_lumina,
-         "samplers": gen_samplers}[w]()
+         "samplers": gen_samplers, "checkpoint_keys": gen_checkpoint_keys}[w]()

@@ -312,3 +312,28 @@ def test_mask_to_kv_len_accepts_only_prefix_key_padding_masks():
         mask_to_kv_len(km.float(), 4, 7)
     with pytest.raises(ValueError):
         mask_to_kv_len(km, 3, 7)
+
+
+def test_bench_picks_the_dominant_kernel_family_from_the_profile():
+    """bench.py's roofline object names the hand-written kernel with the largest measured share of the step (round 1
+    hard-coded the attention forward)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("vft_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = {"attn_fwd_d64": {"launches": 280, "work": 2 * 3.0e13, "ms": 2 * 27.0},
+            "attn_bwd_d64": {"launches": 280, "work": 2 * 7.5e13, "ms": 2 * 86.0},
+            "linear_fwd": {"launches": 2800, "work": 2 * 2.0e14, "ms": 2 * 170.0},
+            "conv3x3_fwd": {"launches": 92, "work": 2 * 3.9e13, "ms": 2 * 35.0},
+            "lora_down": {"launches": 2800, "work": 2 * 4.0e10, "ms": 2 * 10.0},
+            "norm_fwd": {"launches": 420, "work": 2 * 3.0e10, "ms": 2 * 7.0}, "norm_bwd": {"launches": 420, "work": 2 * 4.5e10, "ms": 2 * 12.0}}
+    fam = bench.family_table(prof, 2)
+    assert max(fam, key=lambda k: fam[k]["ms_per_step"]) == "linear_gemm"
+    assert fam["linear_gemm"]["bound"] == "mfma" and fam["linear_gemm"]["ms_per_step"] == 170.0
+    assert abs(fam["linear_gemm"]["achieved"] - 2.0e14 / 0.170 / 1e12) < 0.1 and fam["linear_gemm"]["launches_per_step"] == 1400
+    assert fam["attention_bwd"]["frac"] == round(7.5e13 / 0.086 / 2.5e15, 4)
+    assert fam["norms_activations"]["bound"] == "hbm" and fam["norms_activations"]["ms_per_step"] == 19.0
+    assert fam["lora_rank"]["unit"] == "GB/s"
+    assert bench.physical_cores() >= 1

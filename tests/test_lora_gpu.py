@@ -9,6 +9,19 @@ from .helpers import load_golden, rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["gemm_fused", "adapter_passes"], autouse=True)
+def lora_path(request):
+    """Every test runs on both compositions: the adapter inside the projection GEMM (vft_linear_fwd with the rank
+    extension, the default) and the round-1 one (library GEMM + in-place adapter passes, also the fallback for shapes
+    the fused GEMM does not take)."""
+    from vision_ft_amd import kernels
+
+    old = kernels.FUSED_LORA_GEMM
+    kernels.FUSED_LORA_GEMM = request.param == "gemm_fused"
+    yield request.param
+    kernels.FUSED_LORA_GEMM = old
+
+
 def _case(gpu, M, K, N, r, s=0.5, bias=True, seed=0, lead=None):
     from vision_ft_amd import kernels
 

@@ -13,6 +13,7 @@ from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig  # noqa
 from vision_ft_amd.models.auraflow import AuraFlowConig, Denoiser  # noqa: E402
 from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity, prepare_noised_latents  # noqa: E402
 from vision_ft_amd.modules.timestep.sampling import sigmoid_randn  # noqa: E402
+from vision_ft_amd.models.auraflow.pipeline import AuraFlowModel  # noqa: E402
 from vision_ft_amd.trainer.common import Trainer  # noqa: E402
 from vision_ft_amd.trainer.tasks import DenoiserTask  # noqa: E402
 
@@ -20,10 +21,8 @@ from vision_ft_amd.trainer.tasks import DenoiserTask  # noqa: E402
 class AuraFlowForTraining(DenoiserTask):
     model_config_class = AuraFlowConig
     latent_channels = 4
-    tensor_prefix = "model."
+    pipeline_class = AuraFlowModel
 
-    def build_denoiser(self) -> torch.nn.Module:
-        return Denoiser(self.model_config.denoiser)
 
     def make_conditions(self, batch, width, height, seed):
         dev = self.accelerator.device

@@ -15,6 +15,7 @@ from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig  # noqa
 from vision_ft_amd.models.lumina2 import Denoiser, Lumina2Config, Scheduler  # noqa: E402
 from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity, prepare_noised_latents  # noqa: E402
 from vision_ft_amd.modules.timestep.sampling import shift_fraction_uniform_rand, uniform_rand  # noqa: E402
+from vision_ft_amd.models.lumina2.pipeline import Lumina2  # noqa: E402
 from vision_ft_amd.trainer.common import Trainer  # noqa: E402
 from vision_ft_amd.trainer.tasks import DenoiserTask  # noqa: E402
 
@@ -32,11 +33,9 @@ class Lumina2ForTextToImageTrainingConfig(Lumina2Config):
 class Lumina2ForTextToImageTraining(DenoiserTask):
     model_config_class = Lumina2ForTextToImageTrainingConfig
     latent_channels = 16
-    tensor_prefix = "model.diffusion_model."
+    pipeline_class = Lumina2
     graph_safe = False  # the ragged batch assembly reads caption lengths on the host once per step
 
-    def build_denoiser(self) -> torch.nn.Module:
-        return Denoiser(self.model_config.denoiser)
 
     def make_conditions(self, batch, width, height, seed):
         dev = self.accelerator.device

@@ -18,6 +18,7 @@ from vision_ft_amd.models.sdxl import Denoiser, SDXLConfig  # noqa: E402
 from vision_ft_amd.models.sdxl.util import convert_to_comfy_key  # noqa: E402
 from vision_ft_amd.modules.loss.diffusion import loss_with_predicted_noise, prepare_noised_latents  # noqa: E402
 from vision_ft_amd.modules.timestep.sampling import uniform_randint  # noqa: E402
+from vision_ft_amd.models.sdxl.pipeline import SDXLModel  # noqa: E402
 from vision_ft_amd.trainer.common import Trainer  # noqa: E402
 from vision_ft_amd.trainer.tasks import DenoiserTask  # noqa: E402
 
@@ -29,10 +30,8 @@ class SDXLForTextToImageTrainingConfig(SDXLConfig):
 class SDXLForTextToImageTraining(DenoiserTask):
     model_config_class = SDXLForTextToImageTrainingConfig
     latent_channels = 4
-    tensor_prefix = "model.diffusion_model."
+    pipeline_class = SDXLModel
 
-    def build_denoiser(self) -> torch.nn.Module:
-        return Denoiser(self.model_config.denoiser)
 
     def make_conditions(self, batch, width, height, seed):
         dev = self.accelerator.device

@@ -524,7 +524,7 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
     Lin8Params q{};
     q.x = p.x, q.w = p.w, q.y = p.y, q.bias = p.bias, q.res = p.res, q.ex = p.ex, q.ew = p.ew;
     q.M = M, q.N = N, q.K = K, q.r = p.r, q.ldx = ldx, q.ldw = ldw, q.ldy = ldy, q.ldres = ldres;
-    if (g_variant >= 0 && vft_lin8_fits(q, false)) {
+    if (g_variant >= 0 && q.r <= 16 && vft_lin8_fits(q, false)) {
         vft_lin8_launch(q, g_variant > 0 ? g_variant : vft_lin8_pick(M, N, K), false, (hipStream_t)stream);
         VFT_CHECK_LAUNCH("vft_linear_fwd");
         return 0;

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
                 pt[row][j >> 1] = pr;
             }
         }
-        if (p_out != nullptr && j < r && m0 + row < M) p_out[(int64_t)(m0 + row) * r + j] = (bf16_t)v;
+        // (vft_lora_down, N == 0: the activations leave pre-scaled, so that consumers add them with the adapter's alpha / rank
+        // already applied)
+        if (p_out != nullptr && j < r && m0 + row < M) p_out[(int64_t)(m0 + row) * r + j] = (bf16_t)(N == 0 ? v * s : v);
     }
     __syncthreads();
     if (N == 0) return;  // vft_lora_down: only the rank-r activations are wanted
@@ -372,11 +374,11 @@ extern "C" int vft_lora_fwd(const void* x, void* y, const void* lora_down, const
 // t[M][r] = x[M][K] . lora_down[r][K]^T only (the low-rank activations; the update itself is applied by the consumer:
 // vft_geglu_lora_*, or the rank extension of vft_linear_fwd / vft_linear_nf4)
 extern "C" int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
-                             void* stream) {
+                             float scale, void* stream) {
     if (chk(x && lora_down && t_out, "vft_lora_down: null pointer")) return 1;
     VFT_CHECK_ARG(M > 0 && K > 0 && r > 0 && r <= 16 && K % 8 == 0 && ldx % 8 == 0, "vft_lora_down: need M,K>0, 0<r<=16, K and ldx multiples of 8");
     VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)lora_down) & 15) == 0, "vft_lora_down: operands must be 16-byte aligned");
-    launch_rows<true>(x, nullptr, lora_down, nullptr, t_out, nullptr, nullptr, 0, M, K, 0, r, ldx, 0, 1.f, (hipStream_t)stream);
+    launch_rows<true>(x, nullptr, lora_down, nullptr, t_out, nullptr, nullptr, 0, M, K, 0, r, ldx, 0, scale, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_lora_down");
     return 0;
 }

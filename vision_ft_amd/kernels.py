@@ -183,6 +183,10 @@ def _ready(*tensors: torch.Tensor) -> None:
 
 KIND_LAYER, KIND_RMS, KIND_NONE = 0, 1, 2
 
+# LoRA layers over bf16 bases run on the fused projection GEMM (base + bias + adapter + skip in one launch per
+# direction).  False restores the round-1 composition (library GEMM + in-place adapter passes) for A/B runs.
+FUSED_LORA_GEMM = True
+
 
 def _bf16_or_none(t):
     if t is None:
@@ -609,15 +613,155 @@ class _LoRALinear(torch.autograd.Function):
         return dx, None, None, dA, dB, None, None, dres
 
 
-def lora_down(x2: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
-    """t = x2 @ A^T (M, r): the adapter's low-rank activations (vft_lora_down); no autograd."""
+def lora_down(x2: torch.Tensor, A: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """t = scale * (x2 @ A^T) (M, r): the adapter's low-rank activations (vft_lora_down); no autograd."""
     M, K = x2.shape
     r = A.shape[0]
     t = torch.empty((M, r), dtype=torch.bfloat16, device=x2.device)
     with torch.cuda.device(x2.device), _Timed("lora_down", 2.0 * M * K):
-        st = _C.lib().vft_lora_down(_ptr(x2), _ptr(A), _ptr(t), M, K, r, x2.stride(0), _stream())
+        st = _C.lib().vft_lora_down(_ptr(x2), _ptr(A), _ptr(t), M, K, r, x2.stride(0), float(scale), _stream())
     _C.check(st, "vft_lora_down")
     return t
+
+
+# ---------------------------------------------------------------------------------------------
+# LoRA layers on the fused projection GEMM (vft_linear_fwd, csrc/linear8.hip): ONE GEMM launch per direction computes
+# the frozen base product, the bias, the adapter update (as r extra K columns) and the block's skip connection, so the
+# adapter no longer costs a read-modify-write pass over y / dx.  The rank-r activations come pre-scaled from
+# vft_lora_down (t = s x A^T, u = s dy B), so lora_up / lora_down enter the GEMM as stored and the weight gradients
+# need no further scaling: dA = u^T x, dB = dy^T t.
+# ---------------------------------------------------------------------------------------------
+def _ext_rank(r: int) -> int:
+    """Rank the GEMM's extension runs at (4, 8 or 16): smaller / odd ranks are zero-padded."""
+    return 4 if r <= 4 else 8 if r <= 8 else 16
+
+
+def _pad_rank_rows(A: torch.Tensor, rp: int) -> torch.Tensor:  # (r, K) -> (rp, K)
+    return A if A.shape[0] == rp else torch.cat([A, A.new_zeros(rp - A.shape[0], A.shape[1])], 0)
+
+
+def _pad_rank_cols(B: torch.Tensor, rp: int) -> torch.Tensor:  # (N, r) -> (N, rp)
+    return B if B.shape[1] == rp else torch.cat([B, B.new_zeros(B.shape[0], rp - B.shape[1])], 1)
+
+
+def _transposed_weight(weight: torch.Tensor) -> torch.Tensor:
+    """W^T (in, out) contiguous: the data gradient dy . W is the same NT GEMM on it.  Frozen weights keep the copy
+    on the parameter object (288 GB of HBM: memory is not the constraint); trainable ones are transposed per call."""
+    def make():
+        return weight.detach().t().contiguous()
+
+    if weight.requires_grad:
+        return make()
+    hit = getattr(weight, "_vft_wt", None)
+    if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
+        hit = (weight._version, weight.data_ptr(), make())
+        if not torch.cuda.is_current_stream_capturing():  # a captured tensor lives in the graph's private pool
+            weight._vft_wt = hit
+    return hit[2]
+
+
+def fused_lora_eligible(weight: torch.Tensor, r: int) -> bool:
+    """bf16 weight whose two dimensions are multiples of 64 (forward reduces over in, the data gradient over out),
+    rank at most 16."""
+    return (weight.dtype == torch.bfloat16 and weight.dim() == 2 and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
+            and r <= 16 and weight.is_cuda)
+
+
+def _bf16_rows(t: torch.Tensor | None) -> torch.Tensor | None:
+    if t is None:
+        return None
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(-1) != 1 or t2.stride(0) % 8 != 0 or t2.dtype != torch.bfloat16 or t2.data_ptr() % 16 != 0:
+        t2 = t2.to(torch.bfloat16).contiguous()
+    return t2
+
+
+class _LoRALinearFused(torch.autograd.Function):
+    """residual + x W^T + b + s (x A^T) B^T, one GEMM launch per direction (reference: LoRALinear.forward,
+    src/modules/peft/lora.py:92-104 = three GEMMs, a scale and an add; the residual is the transformer block's
+    `x + layer(x)`, src/models/sdxl/denoiser.py:273-284)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, A, B, s, residual=None):
+        x2 = _rows(x)
+        r = A.shape[0]
+        rp = _ext_rank(r)
+        A_p, B_p = _pad_rank_rows(A.contiguous(), rp), _pad_rank_cols(B.contiguous(), rp)
+        res2 = _bf16_rows(residual)
+        with torch.cuda.device(x.device):
+            t = lora_down(x2, A_p, s)  # (M, rp), pre-scaled
+            y2 = linear_fused(x2, weight, _bf16_or_none(bias), residual=res2, ext_x=t, ext_w=B_p)
+        ctx.save_for_backward(x2, t, weight, A_p, B_p)
+        ctx.s, ctx.r, ctx.xshape = s, r, x.shape
+        ctx.res_shape = residual.shape if residual is not None else None
+        return y2.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t, weight, A_p, B_p = ctx.saved_tensors
+        s, r = ctx.s, ctx.r
+        dy2 = _bf16_rows(dy)
+        dx = dA = dB = None
+        with torch.cuda.device(dy.device):
+            u = lora_down(dy2, B_p.t().contiguous(), s)  # (M, rp) = s dy B
+            if ctx.needs_input_grad[0]:
+                dx2 = linear_fused(dy2, _transposed_weight(weight), None, ext_x=u, ext_w=A_p.t().contiguous())
+                dx = dx2.view(ctx.xshape)
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                dA, dB = _lora_wgrad2(x2, u, dy2, t, A_p, B_p, 1.0)
+                dA, dB = dA[:r], dB[:, :r]
+        dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[6] else None
+        return dx, None, None, dA, dB, None, dres
+
+
+class _LoRAQKVFused(torch.autograd.Function):
+    """q, k, v of SDXL's SelfAttention (three LoRA-wrapped bias-free projections of one input,
+    src/models/sdxl/denoiser.py:32-94) as ONE GEMM per direction over the concatenated frozen weights, the three
+    adapters as one rank-3r extension: A_cat = [Aq; Ak; Av] (3r, C), B_blk = blockdiag(Bq, Bk, Bv) (3N, 3r).
+    Forward returns (B,H,S,D) views of the (tokens, 3N) output; backward takes the attention kernel's single
+    dq|dk|dv buffer."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, s, heads):
+        Bsz, S, C = x.shape
+        x2 = _rows(x)
+        r, N = Aq.shape[0], Bq.shape[0]
+        rp = _ext_rank(3 * r)
+        A_cat = _pad_rank_rows(torch.cat([Aq, Ak, Av], 0), rp)
+        B_blk = _pad_rank_cols(torch.block_diag(Bq, Bk, Bv), rp)
+        with torch.cuda.device(x.device):
+            t = lora_down(x2, A_cat, s)
+            y = linear_fused(x2, wqkv, None, ext_x=t, ext_w=B_blk)  # (M, 3N)
+        ctx.save_for_backward(x2, wqkv, t, A_cat, B_blk)
+        ctx.s, ctx.r, ctx.N, ctx.xshape = s, r, N, x.shape
+        y5 = y.view(Bsz, S, 3, heads, N // heads)
+        return tuple(y5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x2, wqkv, t, A_cat, B_blk = ctx.saved_tensors
+        s, r, N = ctx.s, ctx.r, ctx.N
+        M = x2.shape[0]
+        esz = dq.element_size()
+        fused = (dq.dtype == torch.bfloat16 and dq.stride() == dk.stride() == dv.stride() and dq.stride(3) == 1
+                 and dq.stride(1) * dq.shape[1] == N and dq.stride(2) == 3 * N and dq.stride(0) == dq.shape[2] * 3 * N
+                 and dk.data_ptr() == dq.data_ptr() + N * esz and dv.data_ptr() == dq.data_ptr() + 2 * N * esz)
+        if fused:
+            dy = torch.as_strided(dq, (M, 3 * N), (3 * N, 1))
+        else:
+            dy = torch.cat([g.permute(0, 2, 1, 3).reshape(M, N) for g in (dq, dk, dv)], dim=1).to(torch.bfloat16)
+        grads = [None] * 6
+        with torch.cuda.device(dy.device):
+            u = lora_down(dy, B_blk.t().contiguous(), s)  # (M, rp) = s dy blockdiag(B)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = linear_fused(dy, _transposed_weight(wqkv), None, ext_x=u, ext_w=A_cat.t().contiguous()).view(ctx.xshape)
+            if any(ctx.needs_input_grad[2:8]):
+                dA_cat, dB_blk = _lora_wgrad2(x2, u, dy, t, A_cat, B_blk, 1.0)
+                for i in range(3):
+                    grads[2 * i] = dA_cat[i * r:(i + 1) * r]
+                    grads[2 * i + 1] = dB_blk[i * N:(i + 1) * N, i * r:(i + 1) * r]
+        return (dx, None, *grads, None, None)
 
 
 class _LoRAQKV(torch.autograd.Function):
@@ -695,6 +839,8 @@ def lora_qkv(x: torch.Tensor, wqkv: torch.Tensor, adapters, scale: float, heads:
     _ready(x, wqkv)
     _require_gpu(x, wqkv)
     (Aq, Bq), (Ak, Bk), (Av, Bv) = adapters
+    if FUSED_LORA_GEMM and fused_lora_eligible(wqkv, 3 * Aq.shape[0]) and Bq.shape[0] % 64 == 0:
+        return _LoRAQKVFused.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads))
     return _LoRAQKV.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads))
 
 
@@ -870,6 +1016,10 @@ def lora_geglu_down(x: torch.Tensor, up_base, up_A, up_B, s1: float, down_base, 
     `_GeGLUDown` / `_LoRALinearDeferred`."""
     _ready(x, up_A, up_B, down_A, down_B)
     _require_gpu(x, up_A, up_B, down_A, down_B)
+    if (FUSED_LORA_GEMM and fused_lora_eligible(up_base.weight, up_A.shape[0]) and fused_lora_eligible(down_base.weight, down_A.shape[0])):
+        # both adapters ride in their projection's GEMM (forward and data gradient): plain GEGLU in between
+        proj = _LoRALinearFused.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1), None)
+        return _LoRALinearFused.apply(geglu(proj), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual)
     proj, t1 = _LoRALinearDeferred.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1))
     return _GeGLUDown.apply(proj, t1, up_B.detach(), float(s1), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual)
 
@@ -930,6 +1080,8 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
     if lora_down.shape[0] > 16:
         raise ValueError(f"LoRA rank {lora_down.shape[0]} > 16 is not supported by the MI355X kernels")
     if type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16:
+        if FUSED_LORA_GEMM and fused_lora_eligible(base.weight, lora_down.shape[0]):
+            return _LoRALinearFused.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), residual)
         return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None, residual)
     if hasattr(base, "quant_state"):  # NF4Linear: dequant-fused GEMM for the base products
         q = base.quant_state()

@@ -12,7 +12,7 @@ from .denoiser import Denoiser
 
 DENOISER_TENSOR_PREFIX = "model."
 VAE_TENSOR_PREFIX = "vae."
-TEXT_ENCODER_TENSOR_PREFIX = "text_encoder."
+TEXT_ENCODER_TENSOR_PREFIX = "text_encoders.pile_t5xl.transformer."  # src/models/auraflow/text_encoder.py:50
 
 
 def convert_from_original_key(key: str) -> str:

@@ -195,8 +195,10 @@ class RoPEEmbedder:
     def precompute(dims: list[int], ends: list[int], theta: float) -> list[tuple[torch.Tensor, torch.Tensor]]:
         out = []
         for d, e in zip(dims, ends):
-            inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
-            ang = torch.outer(torch.arange(e, dtype=torch.float64), inv).float()
+            # (explicit device: the tables are plain tensors, not parameters — a `torch.device("meta")` construction
+            # context, as used when a checkpoint is about to be assigned, must not turn them into meta tensors)
+            inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device="cpu") / d))
+            ang = torch.outer(torch.arange(e, dtype=torch.float64, device="cpu"), inv).float()
             out.append((torch.cos(ang), torch.sin(ang)))
         return out
 

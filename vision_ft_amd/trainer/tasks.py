@@ -9,7 +9,6 @@ step can be replayed from a HIP graph."""
 from __future__ import annotations
 
 import torch
-from safetensors.torch import load_file
 
 from ..dataset.synthetic import make_latents
 from ..models.for_training import ModelForTraining
@@ -20,10 +19,7 @@ from ..utils.dtype import str_to_dtype
 class DenoiserTask(ModelForTraining):
     graph_safe = True
     latent_channels = 4
-    tensor_prefix = ""  # checkpoint key prefix of the denoiser weights
-
-    def build_denoiser(self) -> torch.nn.Module:
-        raise NotImplementedError
+    pipeline_class: type[torch.nn.Module]  # models/<family>/pipeline.py: holds `.denoiser`, loads checkpoints
 
     def make_conditions(self, batch: int, width: int, height: int, seed: int) -> dict[str, torch.Tensor]:
         raise NotImplementedError
@@ -33,17 +29,30 @@ class DenoiserTask(ModelForTraining):
 
     # ---- ModelForTraining protocol -----------------------------------------------------------
     def setup_model(self) -> None:
+        """Reference tasks: `init_empty_weights()` -> pipeline -> `_from_checkpoint()` (train/sdxl/text_to_image.py:34-42):
+        original key names are converted, pre-quantised (NF4) Linears are recognised by their checkpoint keys, the
+        state dict is assigned strictly.  `checkpoint_path: random` keeps the default initialisation (benchmarks)."""
         dev = self.accelerator.device
         dtype = str_to_dtype(self.model_config.dtype)
-        with torch.device(dev):
-            self.model = self.build_denoiser()
-        self.model.to(dtype)
         path = self.model_config.checkpoint_path
-        if path not in ("", "random", None):
-            sd = load_file(path)
-            pre = self.tensor_prefix
-            sd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)} if pre and any(k.startswith(pre) for k in sd) else sd
-            self.model.load_state_dict(sd, strict=True)
+        if path in ("", "random", None):
+            with torch.device(dev):
+                pipe = self.pipeline_class(self.model_config)
+            pipe.denoiser.to(dtype)
+        else:
+            with torch.device("meta"):
+                pipe = self.pipeline_class(self.model_config)
+            pipe._from_checkpoint()
+            pipe.denoiser.to(device=dev)
+            for mod in pipe.denoiser.modules():  # floating-point weights in the run's dtype; packed NF4 payloads stay as they are
+                if not hasattr(mod, "quant_state"):
+                    for p_ in mod.parameters(recurse=False):
+                        if p_.is_floating_point():
+                            p_.data = p_.data.to(dtype)
+                    for b_name, b_ in list(mod.named_buffers(recurse=False)):
+                        if b_ is not None and b_.is_floating_point():
+                            setattr(mod, b_name, b_.to(dtype))
+        self.model = pipe.denoiser
         self._static: dict = {}
 
     def after_setup_model(self) -> None:
