@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests take their ranks from a fork server that is started HERE, before anything in this process
+    # touches the GPU: the ranks are then forked from a clean process (a process that has initialised HIP must neither
+    # fork GPU work nor exec another program on the GPU boxes).
+    import multiprocessing
+    from multiprocessing import forkserver
+
+    multiprocessing.get_context("forkserver")
+    forkserver.ensure_running()
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,52 @@
+"""Rank body of tests/test_dp_gpu.py: one data-parallel rank of the tiny SDXL-LoRA trainer.  Imported by the ranks that
+the fork server creates (a module of its own so that they can find it by name)."""
+from __future__ import annotations
+
+import os
+
+
+def config(tmp_path: str, hip_graph: bool, accum: int = 1, clip: float | None = 0.05):
+    from vision_ft_amd.config import TrainConfig
+
+    return TrainConfig.model_validate({
+        "model": {"checkpoint_path": "random", "dtype": "bfloat16", "max_token_length": 75,
+                  "denoiser": {"hidden_dim": 64, "block_out_channels": [64, 128, 128], "context_dim": 64,
+                               "num_transformers_per_block": [1, 1, 2]}},
+        "peft": {"config": {"type": "lora", "rank": 4, "alpha": 1.0}, "include_keys": ["attn1", "attn2", ".ff."],
+                 "exclude_keys": ["text_encoder", "vae"]},
+        "dataset": {"batch_size": 2, "bucket_base_size": 256, "step": 64, "min_size": 128, "samples_per_bucket": 6,
+                    "buckets_wh": [[256, 256], [192, 320]], "num_workers": 0, "shuffle": False},
+        "optimizer": {"name": "torch.optim.AdamW", "args": {"lr": 1e-3}},
+        "saving": None,
+        "trainer": {"hip_graph": hip_graph, "gradient_accumulation_steps": accum, "clip_grad_norm": clip, "tuned_gemms": False},
+        "num_train_epochs": 1,
+    })
+
+
+def run_rank(rank: int, world: int, port: int, out_dir: str, hip_graph: bool) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      VFT_FORCE_DEVICE="0", VFT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from train.sdxl.text_to_image import SDXLForTextToImageTraining
+    from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig
+    from vision_ft_amd.trainer.common import Trainer
+
+    try:
+        trainer = Trainer(config(out_dir, hip_graph))
+        trainer.register_train_dataset_class(SyntheticLatentDatasetConfig)
+        trainer.register_model_class(SDXLForTextToImageTraining)
+        trainer.train()
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu() for k, v in trainer.raw_model.model.state_dict().items() if ".lora_" in k}
+        torch.save({"lora": sd, "losses": list(trainer.losses), "steps_per_epoch": len(trainer.train_dataloader),
+                    "world": trainer.accelerator.world, "side_stream": trainer.dp.stream is not None}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()

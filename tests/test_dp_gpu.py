@@ -1,0 +1,96 @@
+"""GPU rehearsal of the N>1 training path on a one-GPU box: two ranks share cuda:0 and exchange gradients over gloo
+(VFT_FORCE_DEVICE / VFT_DIST_BACKEND hooks of trainer.init_distributed), which exercises everything of the data-parallel
+step except the RCCL transport itself: sharding with equal step counts, the flat gradient buffer, the all-reduce on the
+side stream, clipping after the exchange, and — in graph mode — the split forward/backward | clip | optimizer graphs.
+The ranks are forked from the clean fork server that tests/conftest.py starts before any GPU call."""
+import multiprocessing
+import os
+
+import pytest
+import torch
+
+from .dp_rehearsal_worker import config, run_rank
+
+pytestmark = pytest.mark.gpu
+
+
+def _spawn(tmp_path, hip_graph: bool, tag: str):
+    out = tmp_path / tag
+    out.mkdir()
+    ctx = multiprocessing.get_context("forkserver")
+    port = 32500 + (os.getpid() % 2000) + (7 if hip_graph else 0)
+    procs = [ctx.Process(target=run_rank, args=(r, 2, port, str(out), hip_graph)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return [torch.load(out / f"rank{r}.pt") for r in range(2)]
+
+
+def _reference_mean_gradient_run(gpu, tmp_path):
+    """One process, same data: per optimizer step the two ranks' micro-batches (dataset items r, r+2, ...) with the loss
+    halved, i.e. the mean gradient; each micro-batch restarts from the RNG state of that step, as both ranks (seeded alike)
+    draw the same noise / timesteps for their different data; clip, AdamW."""
+    import sys
+
+    sys.path.insert(0, ".")
+    from train.sdxl.text_to_image import SDXLForTextToImageTraining
+    from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig
+    from vision_ft_amd.trainer.common import Trainer
+
+    tr = Trainer(config(str(tmp_path), hip_graph=False))
+    tr.register_train_dataset_class(SyntheticLatentDatasetConfig)
+    tr.register_model_class(SDXLForTextToImageTraining)
+    tr.before_train()
+    tr.raw_model.sanity_check()
+    tr.raw_model.before_train_epoch()
+    batches = list(tr.train_dataloader)
+    assert len(batches) == 6
+    params = [p for p in tr.model.parameters() if p.requires_grad]
+    losses = [[], []]
+    for j in range(3):
+        state = torch.cuda.get_rng_state()
+        for r in range(2):
+            torch.cuda.set_rng_state(state)
+            loss = tr.model(batches[2 * j + r])
+            (loss / 2).backward()
+            losses[r].append(float(loss))
+        torch.nn.utils.clip_grad_norm_(params, 0.05)
+        tr.optimizer.step()
+        tr.dp.zero_grad()
+    sd = {k: v.detach().cpu() for k, v in tr.raw_model.model.state_dict().items() if ".lora_" in k}
+    return sd, losses
+
+
+def _dist(a, b):
+    num = sum(((a[k].float() - b[k].float()) ** 2).sum() for k in a) ** 0.5
+    den = sum((b[k].float() ** 2).sum() for k in a) ** 0.5
+    return float(num / den)
+
+
+def test_two_ranks_on_one_gpu_match_the_mean_gradient_run(gpu, tmp_path):
+    eager = _spawn(tmp_path, hip_graph=False, tag="eager")
+    assert all(r["world"] == 2 and r["steps_per_epoch"] == 3 and r["side_stream"] and len(r["losses"]) == 3 for r in eager)
+    for k in eager[0]["lora"]:  # replicas stay bit-identical
+        assert torch.equal(eager[0]["lora"][k], eager[1]["lora"][k]), k
+    assert eager[0]["losses"] != eager[1]["losses"]  # the ranks really saw different data
+    ref, ref_losses = _reference_mean_gradient_run(gpu, tmp_path)
+    # first-step losses do not depend on any update: the same kernels on the same inputs
+    assert abs(eager[0]["losses"][0] - ref_losses[0][0]) < 2e-3 * abs(ref_losses[0][0])
+    assert abs(eager[1]["losses"][0] - ref_losses[1][0]) < 2e-3 * abs(ref_losses[1][0])
+    moved = _dist({k: torch.zeros_like(v) for k, v in ref.items() if "lora_up" in k}, {k: v for k, v in ref.items() if "lora_up" in k})
+    assert moved == 1.0 and any(v.abs().sum() > 0 for k, v in ref.items() if "lora_up" in k)
+    # Adam normalises the update, so bf16 run-to-run noise of the reductions shows in the weights: bounded, small
+    assert _dist(eager[0]["lora"], ref) < 3e-2, _dist(eager[0]["lora"], ref)
+    torch.testing.assert_close(torch.tensor(eager[0]["losses"]), torch.tensor(ref_losses[0]), rtol=5e-3, atol=1e-4)
+    torch.testing.assert_close(torch.tensor(eager[1]["losses"]), torch.tensor(ref_losses[1]), rtol=5e-3, atol=1e-4)
+
+    # HIP-graph mode: forward/backward graph | gradient exchange on the side stream | clip graph | optimizer graph
+    graph = _spawn(tmp_path, hip_graph=True, tag="graph")
+    for k in graph[0]["lora"]:
+        assert torch.equal(graph[0]["lora"][k], graph[1]["lora"][k]), k
+    for r in range(2):
+        assert len(graph[r]["losses"]) == 3
+        assert abs(graph[r]["losses"][0] - eager[r]["losses"][0]) < 5e-3 * abs(eager[r]["losses"][0])
+        assert all(torch.isfinite(torch.tensor(graph[r]["losses"])))

@@ -61,12 +61,14 @@ def set_seed(seed: int) -> None:
 
 
 def init_distributed() -> None:
-    """torchrun / torch.distributed.run environment -> RCCL process group on this rank's GPU."""
+    """torchrun / torch.distributed.run environment -> RCCL process group on this rank's GPU.
+    Rehearsal hooks (tests, bench.py): VFT_FORCE_DEVICE=<i> puts every rank on GPU i and VFT_DIST_BACKEND=gloo
+    exchanges through the host, so the whole N>1 path (sharding, side stream, split graphs) runs on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("VFT_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(os.environ.get("VFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
 
 
 class Trainer:
@@ -169,16 +171,25 @@ class Trainer:
     def backward(self, loss: torch.Tensor, current_step: int | None = None) -> None:
         """reference :355-359.  There DDP all-reduces inside `accelerator.backward` on boundary micro-steps, so
         `after_backward` (gradient clipping) sees the AVERAGED gradient on boundaries and the local one under
-        `no_sync`; the same order here: exchange first on boundaries, then clip."""
+        `no_sync`; the same order here: exchange first on boundaries, then clip.  The exchange is only STARTED here
+        (side stream); `apply_gradients` waits for it, so whatever the loop does in between — reading the loss back
+        for the log, staging the next batch — overlaps with the collective."""
         self.raw_model.before_backward()
         (loss / self.gradient_accumulation_steps).backward()
-        if current_step is not None and current_step % self.gradient_accumulation_steps == 0:
+        self._boundary = current_step is not None and current_step % self.gradient_accumulation_steps == 0
+        if self._boundary:
             self.dp.reduce_async()  # skipped on non-boundary micro-steps == the reference's no_sync (:301-308)
-            self.dp.wait()
-        self.raw_model.after_backward()
+        else:
+            self.raw_model.after_backward()
+
+    _boundary = False
 
     def apply_gradients(self, current_step: int) -> None:
         if current_step % self.gradient_accumulation_steps == 0:
+            if self._boundary:
+                self.dp.wait()
+                self.raw_model.after_backward()  # clipping on the averaged gradient
+                self._boundary = False
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
@@ -195,6 +206,11 @@ class Trainer:
         self.accelerator.wait_for_everyone()
 
     def training_loop(self) -> None:
+        """One optimizer step per accumulation boundary.  Order on a boundary: forward + backward (graph A) ->
+        gradient exchange STARTS on the side stream -> host work that does not need the update (loss read-back for the
+        log, the next batch staged into its static tensors) -> wait -> clip -> optimizer (graph B) -> LR scheduler ->
+        checkpoint cadence.  The collective therefore overlaps with the logging and the next batch's staging; the next
+        forward needs the updated weights and cannot start earlier."""
         step = 0
         graphs: dict = {}
         use_graph = (self.config.trainer.hip_graph and torch.cuda.is_available()
@@ -203,11 +219,16 @@ class Trainer:
         opt_graph = None  # shared optimizer graph when the step is split (DP or accumulation)
         for epoch in range(1, self.config.num_train_epochs + 1):
             self.raw_model.before_train_epoch()
-            for batch in self.train_dataloader:
+            it = iter(self.train_dataloader)
+            batch = next(it, None)
+            staged = False
+            while batch is not None:
                 step += 1
                 self.raw_model.before_train_step()
+                boundary = step % ga == 0
+                nxt = None
                 if use_graph:
-                    key = self.raw_model.stage_batch(batch)  # copies the batch into static tensors
+                    key = self.raw_model._key if staged else self.raw_model.stage_batch(batch)  # batch -> static tensors
                     if key not in graphs:
                         from .graph import GraphedTrainStep
 
@@ -216,21 +237,30 @@ class Trainer:
                                                        after_backward=self.raw_model.after_backward, split=ga > 1 or None,
                                                        opt_graph=opt_graph, pool=first.pool() if first is not None else None,
                                                        loss_scale=1.0 / ga)
+                        graphs[key].defer_finish = True
                         opt_graph = graphs[key].graph_b
-                    boundary = step % ga == 0
                     loss = graphs[key](boundary)
+                    if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
+                        self.losses.append(float(loss.detach()))
+                    nxt = next(it, None)
+                    staged = nxt is not None and self.debug_mode != "1step"
+                    if staged:
+                        self.raw_model.stage_batch(nxt)  # queued behind graph A; the exchange runs beside it
+                    graphs[key].finish()
                     if boundary and self.scheduler is not None:
                         self.scheduler.step()
                 else:
                     loss = self.model(batch)
                     self.backward(loss, step)
+                    if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
+                        self.losses.append(float(loss.detach()))
+                    nxt = next(it, None)
                     self.apply_gradients(step)
-                if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
-                    self.losses.append(float(loss.detach()))
                 self.call_saving_callbacks(epoch, step)
                 self.raw_model.after_train_step()
                 if self.debug_mode == "1step":
                     break
+                batch = nxt
             self.raw_model.after_train_epoch()
             if self.debug_mode == "1step":
                 break
