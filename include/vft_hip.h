@@ -68,6 +68,9 @@ int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides,
                  const int64_t* dk_strides, const int64_t* dv_strides, float scale, int64_t ws_floats,
                  void* stream);
+/* Tuning / A-B control of the attention kernels (process-wide; the trainers never call it): 0 = automatic (8-wave
+ * kernels for head_dim >= 128), 1 = the 4-wave kernels for every head_dim. */
+int vft_attn_variant(int variant);
 
 /* ---- LoRA -----------------------------------------------------------------------------------
  * Replace the low-rank branch of LoRALinear.forward, src/modules/peft/lora.py:92-104

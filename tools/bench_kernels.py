@@ -48,24 +48,34 @@ def lora():
 
 
 def attn():
-    print("== attention (TFLOP/s: fwd 4BHSSD, bwd algorithmic 10BHSSD) ==")
+    from vision_ft_amd import _C
+
+    print("== attention (TFLOP/s: fwd 4BHSSD, bwd algorithmic 10BHSSD); v1 = 4-wave kernels, v0 = automatic (8-wave for D >= 128) ==")
     for B, H, Hkv, Sq, Sk, D in [(4, 10, 10, 4096, 4096, 64), (4, 20, 20, 1024, 1024, 64), (4, 10, 10, 4096, 77, 64),
-                                 (4, 20, 20, 1024, 77, 64), (2, 12, 12, 4360, 4360, 256), (2, 24, 8, 4352, 4352, 96),
-                                 (16, 16, 16, 2048, 2048, 128)]:
+                                 (4, 20, 20, 1024, 77, 64), (2, 12, 12, 4360, 4360, 256), (4, 12, 12, 4360, 4360, 256),
+                                 (2, 24, 8, 4352, 4352, 96), (16, 16, 16, 2048, 2048, 128)]:
         q = bf(B, Sq, H, D).permute(0, 2, 1, 3).requires_grad_(True)
         k = bf(B, Sk, Hkv, D).permute(0, 2, 1, 3).requires_grad_(True)
         v = bf(B, Sk, Hkv, D).permute(0, 2, 1, 3).requires_grad_(True)
-        o = kernels.flash_attention(q, k, v)
         do = bf(B, Sq, H, D).permute(0, 2, 1, 3)
-        tf = timeit(lambda: kernels.flash_attention(q, k, v))
-
-        def fb():
-            kernels.flash_attention(q, k, v).backward(do)
-
-        tfb = timeit(fb)
         fl = 4.0 * B * H * Sq * Sk * D
-        print(f"B={B} H={H}/{Hkv} Sq={Sq} Sk={Sk} D={D:3d} | fwd {tf*1e6:8.1f} us {fl/tf/1e12:7.1f} TF/s | bwd {(tfb-tf)*1e6:8.1f} us "
-              f"{2.5*fl/(tfb-tf)/1e12:7.1f} TF/s")
+        line = f"B={B} H={H}/{Hkv} Sq={Sq} Sk={Sk} D={D:3d}"
+        outs = []
+        for var in ((1, 0) if D >= 128 else (0,)):
+            _C.lib().vft_attn_variant(var)
+            o = kernels.flash_attention(q, k, v)
+            outs.append(o.detach().float())
+            tf = timeit(lambda: kernels.flash_attention(q, k, v))
+
+            def fb():
+                kernels.flash_attention(q, k, v).backward(do)
+
+            tfb = timeit(fb)
+            line += f" | v{var} fwd {tf*1e6:8.1f} us {fl/tf/1e12:7.1f} TF/s  bwd {(tfb-tf)*1e6:8.1f} us {2.5*fl/(tfb-tf)/1e12:7.1f} TF/s"
+        if len(outs) == 2:
+            line += f" | rel diff {((outs[0]-outs[1]).norm()/outs[0].norm()).item():.1e}"
+        _C.lib().vft_attn_variant(0)
+        print(line, flush=True)
 
 
 def norm():

@@ -22,6 +22,8 @@
 // Backward is two kernels (no atomics, bitwise reproducible): dq (one workgroup per 128 queries, loops
 // over key tiles; also produces delta = rowsum(dO*O)) and dkdv (one workgroup per 128 keys, loops over
 // query tiles). Both recompute P from the saved log-sum-exp.
+#include <type_traits>
+
 #include "vft_common.h"
 
 namespace {
@@ -48,6 +50,9 @@ struct AttnParams {
     float scale;
     Str3 sq, sk, sv, so, sdo, sdq, sdk, sdv;
 };
+
+// A/B control (vft_attn_variant): 0 = automatic, 1 = the 4-wave kernels for every head_dim
+int g_attn_variant = 0;
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -339,6 +344,219 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnPa
 
 
 // =============================================================================================
+// forward, head_dim >= 128: one workgroup = 128 queries x 8 waves.  Wave w serves queries 32 (w & 3) .. +31 and
+// the key half (w >> 2) of every 64-key tile, so the waves w and w + 4 — which share a SIMD — hold the same queries
+// against different keys: each keeps its own running maximum / sum / output accumulator (O: D/2 registers, Q
+// fragments: D/4 — two waves fit a SIMD where the 4-wave kernel above needs the whole register file for one) and the
+// pair is merged once, through LDS, at the end (the split-KV identity  O = (a0 O0 + a1 O1) / (a0 l0 + a1 l1),
+// a_g = 2^(m_g - max m)).  K/V tiles arrive by LDS-DMA (buffer_load ... lds: no staging registers, masked key rows
+// read zeros through the descriptor's bounds check), double-buffered, one barrier per tile.  The LDS image is
+// unpadded (a DMA writes lane-linear) with the 16-byte chunk c of row r stored at chunk
+//     (c & ~15) | ((c & 15) ^ f(r)),   f(r) = ((r & 3) << 2) | ((r >> 2) & 3)
+// which serves both the row reads of K (ds_read_b128, 32 rows x one chunk) and the transposed reads of V
+// (ds_read_b64_tr_b16) without bank conflicts; the swizzle sits on the DMA's per-lane SOURCE chunk.
+// =============================================================================================
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ int swz_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// rows x (D*2)-byte tile by LDS-DMA, 512 threads: wave-instruction i covers 1024 bytes = 1024/(2D) rows.  Nothing is
+// kept per instruction: the lane's row and swizzled source chunk are recomputed at issue (a few VALU operations per
+// 1 KiB moved; the register file is what these kernels are short of).
+template <int D, int ROWS, int NW = 8>
+struct DmaTile {
+    static constexpr int RB = D * 2;                  // bytes per row
+    static constexpr int NI = ROWS * RB / 1024 / NW;  // instructions per wave per tile
+    static constexpr int OOBV = (int)0x80000000u;
+    // rows [row0, row0 + ROWS) of the tensor behind `rs` (row stride in elements); rows >= row_limit read zeros
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int row0, int row_limit, int row_stride_elems) {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int byte = (wv * NI + q) * 1024 + lane * 16;
+            const int r = byte / RB, slot = (byte % RB) >> 4;
+            const int c = (slot & ~15) | ((slot & 15) ^ swz_f(r));
+            const int voff = (row0 + r) * row_stride_elems * 2 + c * 16;
+            dma16(rs, lds_tile + (wv * NI + q) * 1024, row0 + r < row_limit ? voff : OOBV);
+        }
+    }
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;  // bytes of one K (or V) tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), qg = w & 3, g = w >> 2;
+    int qtile, bh;
+    if (!xcd_map((p.Sq + 127) / 128, p.B * p.Hq, qtile, bh)) return;  // block-uniform
+    const int b = bh / p.Hq, hq = bh % p.Hq, q0 = qtile * 128;
+    const int hkv = hq / (p.Hq / p.Hkv);
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* Ob = p.o + b * p.so.b + hq * p.so.h;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((int64_t)(p.Sk - 1) * p.sk.s + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((int64_t)(p.Sk - 1) * p.sv.s + D) * 2), 0x00020000);
+
+    const int qrow = q0 + qg * 32 + r;
+    const bool qok = qrow < p.Sq;
+    bf16x8 Qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+    const float sc = p.scale * kLog2e;
+
+    const int ntiles = (kvl + 63) / 64;
+    typedef DmaTile<D, 64> Stage;
+    const int ks_s = (int)p.sk.s, vs_s = (int)p.sv.s;
+    if (ntiles > 0) {
+        Stage::issue(rk, smem, 0, kvl, ks_s);
+        Stage::issue(rv, smem + TILE, 0, kvl, vs_s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses of this lane (bytes inside a tile).  K rows: row 32 g + r, chunk 2 ks + h;
+    // V transposed: rows 32 g + 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
+    const int krow = 32 * g + r;
+    const int kbase = krow * RB + ((h ^ swz_f(krow)) << 4);  // ^ ((ks & 7) << 5), + (ks >> 3) * 256
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int vbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 32 * g + 4 * h + (i16 >> 2) + 8 * hi;
+        vbase[hi] = vr * RB + ((cc ^ swz_f(vr)) << 4) + (i16 & 1) * 8;  // ^ ((dt & 3) << 6), + (dt >> 2) * 256, + kk * 16 * RB
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const char* Kc = smem + (t & 1) * 2 * TILE;
+        const char* Vc = Kc + TILE;
+        if (t + 1 < ntiles) {  // the other buffer was last read before the barrier that ended tile t-1
+            char* Kn = smem + ((t + 1) & 1) * 2 * TILE;
+            Stage::issue(rk, Kn, (t + 1) * 64, kvl, ks_s);
+            Stage::issue(rv, Kn + TILE, (t + 1) * 64, kvl, vs_s);
+        }
+        // S^T[key][q] = K Q^T for this wave's 32 keys
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kc + ((kbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256));
+            S = mfma32(a, Qf[ks], S);
+        }
+        const int n0 = t * 64 + 32 * g;
+        if (t * 64 + 64 > kvl) {  // block-uniform: only the last key tile can be ragged
+            asm volatile("; ragged tail tile" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = n0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key >= kvl) S[i] = -INFINITY;
+            }
+        }
+        float tmax = S[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, S[i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        // Lazy rescale: the reference exponent m only follows the running maximum when it has grown by more than 2^8
+        // (P then stays below 256: nothing for bf16 / fp32 accumulation), so the D/2-register rescale of O — as much
+        // VALU work as the tile's softmax — runs in the first tiles only instead of in most of them (with 32 queries per
+        // wave SOME row sets a new maximum in nearly every tile).  m, l and O stay mutually consistent, so the result is
+        // the same softmax; the pair merge and the LSE use m as it is.
+        const float ts = tmax * sc;
+        const float m_new = ts > m + 8.f ? ts : m;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pv = __builtin_amdgcn_exp2f(S[i] * sc - m_new);
+            psum += pv;
+            S[i] = pv;
+        }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // exact skip once the running maxima have settled
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+        }
+        bf16x8 Pf[2];
+        Pf[0] = pack8(S, 0);
+        Pf[1] = pack8(S, 1);
+        // O^T[d][q] += V^T P^T over this wave's 32 keys
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const char* a0 = Vc + kk * 16 * RB + (dt >> 2) * 256;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (vbase[0] ^ ((dt & 3) << 6))));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (vbase[1] ^ ((dt & 3) << 6))));
+                s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                O[dt] = mfma32(__builtin_bit_cast(bf16x8, both), Pf[kk], O[dt]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (issued a whole tile of compute ago)
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- merge the wave pair: wave g finalises d-tiles [g DT/2, (g+1) DT/2); it receives the partner's accumulators for
+    //      those tiles (and the partner's m, l) through the K/V buffers, which are idle now ------------------------------
+    constexpr int HT = DT / 2;
+    float4* X = reinterpret_cast<float4*>(smem);           // [8 waves][HT*4 float4][64 lanes]
+    float2* ML = reinterpret_cast<float2*>(smem + 8 * HT * 4 * 64 * 16);  // [8 waves][64 lanes]
+    const float ltot_own = lsum + __shfl_xor(lsum, 32, 64);
+    // (register arrays must be indexed by compile-time constants: the two roles are separate code paths)
+    auto give = [&](auto GIVE0) {  // write the accumulators of the partner's d-tiles
+        constexpr int base = decltype(GIVE0)::value * HT;
+#pragma unroll
+        for (int j = 0; j < HT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                X[(w * HT * 4 + j * 4 + e) * 64 + lane] =
+                    make_float4(O[base + j][4 * e], O[base + j][4 * e + 1], O[base + j][4 * e + 2], O[base + j][4 * e + 3]);
+    };
+    if (g == 0) give(std::integral_constant<int, 1>{}); else give(std::integral_constant<int, 0>{});
+    ML[w * 64 + lane] = make_float2(m, ltot_own);
+    __syncthreads();
+    const int pw = w ^ 4;
+    const float2 pml = ML[pw * 64 + lane];
+    const float mm = fmaxf(m, pml.x);
+    const float a_own = __builtin_amdgcn_exp2f(m - mm), a_par = __builtin_amdgcn_exp2f(pml.x - mm);
+    const float ltot = ltot_own * a_own + pml.y * a_par;
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    auto take = [&](auto MINE) {  // combine, normalise and store this wave's d-tiles
+        constexpr int base = decltype(MINE)::value * HT;
+#pragma unroll
+        for (int j = 0; j < HT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 po = X[(pw * HT * 4 + j * 4 + e) * 64 + lane];
+                bf16_t* dst = Ob + (int64_t)qrow * p.so.s + (base + j) * 32 + 8 * e + 4 * h;
+                store4(dst, (O[base + j][4 * e] * a_own + po.x * a_par) * inv, (O[base + j][4 * e + 1] * a_own + po.y * a_par) * inv,
+                       (O[base + j][4 * e + 2] * a_own + po.z * a_par) * inv, (O[base + j][4 * e + 3] * a_own + po.w * a_par) * inv);
+            }
+    };
+    if (qok) {
+        if (g == 0) take(std::integral_constant<int, 0>{}); else take(std::integral_constant<int, 1>{});
+        if (g == 0 && h == 0 && p.lse) {
+            p.lse[((int64_t)b * p.Hq + hq) * p.Sq + qrow] = ltot > 0.f ? (mm + __log2f(ltot)) * kLn2 : -INFINITY;
+        }
+    }
+}
+
+// =============================================================================================
 // backward dQ: one workgroup = 128 queries, key tiles of 64
 // =============================================================================================
 template <int D>
@@ -476,6 +694,174 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
             for (int g = 0; g < 4; ++g) {
                 bf16_t* dst = dQb + (int64_t)qrow * p.sdq.s + dt * 32 + 8 * g + 4 * h;
                 store4(dst, dQ[dt][4 * g] * s, dQ[dt][4 * g + 1] * s, dQ[dt][4 * g + 2] * s, dQ[dt][4 * g + 3] * s);
+            }
+    }
+}
+
+// =============================================================================================
+// backward dQ, head_dim >= 128, second form: 4 waves x 32 queries, one wave per SIMD (as above: Q / dO fragments and the dQ
+// accumulator take D registers, the rest of the 512-register file pays for read-ahead).  K / V tiles of 64 keys arrive by
+// LDS-DMA into the swizzled unpadded image, double-buffered (a tile is ~100 MFMAs of work: ample cover for the DMA issued
+// at its start); masked key rows read zeros through the descriptor's bounds check.  Row fragments of K and V run PF
+// steps ahead of the S / dP MFMAs, the transposed K fragments TF steps ahead of the dQ MFMAs.
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;
+    typedef DmaTile<D, 64, 4> Stage;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int qtile, bh;
+    if (!xcd_map((p.Sq + 127) / 128, p.B * p.Hq, qtile, bh)) return;  // block-uniform
+    const int b = bh / p.Hq, hq = bh % p.Hq, q0 = qtile * 128;
+    const int hkv = hq / (p.Hq / p.Hkv);
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+    const bf16_t* dOb = p.dout + b * p.sdo.b + hq * p.sdo.h;
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dQb = p.dq + b * p.sdq.b + hq * p.sdq.h;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((int64_t)(p.Sk - 1) * p.sk.s + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((int64_t)(p.Sk - 1) * p.sv.s + D) * 2), 0x00020000);
+    const int ks_s = (int)p.sk.s, vs_s = (int)p.sv.s;
+    const int ntiles = (kvl + 63) / 64;
+    if (ntiles > 0) {
+        Stage::issue(rk, smem, 0, kvl, ks_s);
+        Stage::issue(rv, smem + TILE, 0, kvl, vs_s);
+    }
+
+    const int qrow = q0 + w * 32 + r;
+    const bool qok = qrow < p.Sq;
+    bf16x8 Qf[KS], dOf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+        dOf[ks] = ldg_frag(dOb + (int64_t)qrow * p.sdo.s + ks * 16 + 8 * h, qok);
+    }
+    const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq + qrow;
+    const float lse2 = qok ? p.lse[srow] * kLog2e : INFINITY;
+    // delta = rowsum(dO * O), computed here (this kernel runs first) and published for the dK/dV kernel
+    float dl = 0.f;
+    {
+        const bf16_t* Ob = p.o + b * p.so.b + hq * p.so.h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 of = ldg_frag(Ob + (int64_t)qrow * p.so.s + ks * 16 + 8 * h, qok);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)dOf[ks][j];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (qok && h == 0) p.delta[srow] = dl;
+    }
+    const float sc = p.scale * kLog2e;
+
+    f32x16 dQ[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[dt][i] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses (bytes inside a 64-row tile): row reads: key row 32 kt + r, chunk 2 ks + h; transposed reads:
+    // key rows 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
+    const int rbase = r * RB + ((h ^ swz_f(r)) << 4);
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int tbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 4 * h + (i16 >> 2) + 8 * hi;
+        tbase[hi] = vr * RB + ((cc ^ swz_f(vr)) << 4) + (i16 & 1) * 8;
+    }
+    constexpr int PF = 4, TF = 4;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const char* Kc = smem + (t & 1) * 2 * TILE;
+        const char* Vc = Kc + TILE;
+        if (t + 1 < ntiles) {  // the other buffer was last read before the barrier that ended tile t-1
+            char* Kn = smem + ((t + 1) & 1) * 2 * TILE;
+            Stage::issue(rk, Kn, (t + 1) * 64, kvl, ks_s);
+            Stage::issue(rv, Kn + TILE, (t + 1) * 64, kvl, vs_s);
+        }
+        const int n0 = t * 64;
+        auto rowoff = [&](int st) {  // st = kt * KS + ks
+            const int kt = st / KS, ks = st % KS;
+            return kt * 32 * RB + (rbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256;
+        };
+        bf16x8 ka[PF], va[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            ka[j] = *reinterpret_cast<const bf16x8*>(Kc + rowoff(j));
+            va[j] = *reinterpret_cast<const bf16x8*>(Vc + rowoff(j));
+        }
+        bf16x8 dSf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 S, dP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[i] = 0.f;
+                dP[i] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int st = kt * KS + ks;
+                const bf16x8 a = ka[st % PF], c = va[st % PF];
+                if (st + PF < 2 * KS) {
+                    ka[st % PF] = *reinterpret_cast<const bf16x8*>(Kc + rowoff(st + PF));
+                    va[st % PF] = *reinterpret_cast<const bf16x8*>(Vc + rowoff(st + PF));
+                }
+                S = mfma32(a, Qf[ks], S);
+                dP = mfma32(c, dOf[ks], dP);
+            }
+            if (n0 + 64 > kvl) {  // ragged last tile: masked keys contribute nothing
+                asm volatile("; ragged tail tile" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = n0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= kvl) S[i] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(S[i] * sc - lse2);
+                S[i] = pv * (dP[i] - dl);
+            }
+            dSf[kt * 2] = pack8(S, 0);
+            dSf[kt * 2 + 1] = pack8(S, 1);
+        }
+        // dQ^T[d][q] += K^T dS^T
+        auto trfrag = [&](int st) {  // st = dt * 4 + kk
+            const int dt = st >> 2, kk = st & 3;
+            const int o0 = kk * 16 * RB + (dt >> 2) * 256, x = (dt & 3) << 6;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Kc + o0 + (tbase[0] ^ x)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Kc + o0 + (tbase[1] ^ x)));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        bf16x8 ta[TF];
+#pragma unroll
+        for (int j = 0; j < TF; ++j) ta[j] = trfrag(j);
+#pragma unroll
+        for (int st = 0; st < 4 * DT; ++st) {
+            const bf16x8 a = ta[st % TF];
+            if (st + TF < 4 * DT) ta[st % TF] = trfrag(st + TF);
+            dQ[st >> 2] = mfma32(a, dSf[st & 3], dQ[st >> 2]);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile t+1 has landed (issued a whole tile of compute ago)
+        __builtin_amdgcn_s_barrier();
+    }
+    if (qok) {
+        const float s_ = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bf16_t* dst = dQb + (int64_t)qrow * p.sdq.s + dt * 32 + 8 * e + 4 * h;
+                store4(dst, dQ[dt][4 * e] * s_, dQ[dt][4 * e + 1] * s_, dQ[dt][4 * e + 2] * s_, dQ[dt][4 * e + 3] * s_);
             }
     }
 }
@@ -672,6 +1058,462 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     }
 }
 
+// =============================================================================================
+// backward dK/dV, head_dim >= 128: one workgroup = 128 keys x 8 waves.  A PAIR of waves (w, w ^ 1 — they sit on
+// different SIMDs) owns 32 keys; each wave of the pair owns one HALF of the head dimension: its K / V fragments and its
+// dK / dV accumulators cover D/2 columns (D/4 + D/2 registers instead of D/2 + D, so two waves fit a SIMD).
+// S = Q K^T and dP = dO V^T contract over the whole head dimension: each wave forms the partial sum over its half, the
+// pair's "follower" hands its partials (fp32) to the "leader" through LDS, the leader forms P and dS once for the pair
+// and hands them back packed (bf16), and each wave accumulates its own half of dV^T += dO^T P and dK^T += Q^T dS — no
+// accumulator is shared, the outputs need no merge.  Per query tile (32 queries) that is three phases
+//     A: partial S, dP (MFMA)   | B1: leader: sum + softmax (VALU), DMA issue   | B2: dV, dK (MFMA)
+// separated by workgroup barriers.  Waves 4-7 run the same program ONE BARRIER BEHIND waves 0-3 and the leader of a
+// pair alternates between the groups, so the two waves that share a SIMD are never in the same phase: while one is in
+// its VALU phase (or idle as a follower) the other issues MFMAs.  Q / dO tiles arrive by LDS-DMA into the swizzled
+// unpadded image of the forward kernel, in a ring of three buffers (a tile is issued 1.5 tiles before its first reader,
+// in phase B1, when the slowest group has left the buffer it overwrites); every wave issues the same number of DMAs
+// per tile (its share of Q and dO, 8 floats of lse / delta), so one counted vmcnt per tile retires its share of the
+// next tile one barrier before the first group reads it.
+// =============================================================================================
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 4, voff, 0, 0, 0);
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, HK = KS / 2, HT = DT / 2, RB = D * 2, BQ = 32;
+    constexpr int TILE = BQ * RB;                  // bytes of one Q (or dO) tile
+    constexpr int BUFB = 2 * TILE + 512;           // Q | dO | lse[32] (+ 128 B written by the DMA's upper lanes) | delta[32] (+ 128 B)
+    constexpr int XA = 3 * BUFB;                   // follower -> leader: partial S, dP: 4 pairs x 8 float4 x 64 lanes
+    constexpr int XB = XA + 4 * 8 * 64 * 16;       // leader -> follower: packed P, dS:   4 pairs x 4 uint4 x 64 lanes
+    constexpr int DUMP = XB + 4 * 4 * 64 * 16;     // 256 B per wave: where the filler DMAs of waves 2-7 land
+    constexpr int NDMA = 2 * DmaTile<D, BQ>::NI + 1;  // DMA instructions per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), grp = w >> 2, pair = w >> 1, g = w & 1;
+    const bool lead = ((w & 1) ^ grp) == 0;        // wave-uniform; one leader per SIMD
+    int ktile, bh;
+    if (!xcd_map(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv, ktile, bh)) return;  // block-uniform
+    const int split = ktile % p.nsplit;
+    ktile /= p.nsplit;
+    const int b = bh / p.Hkv, hkv = bh % p.Hkv, n0 = ktile * 128;
+    const int G = p.Hq / p.Hkv;
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dKb = p.dk + b * p.sdk.b + hkv * p.sdk.h;
+    bf16_t* dVb = p.dv + b * p.sdv.b + hkv * p.sdv.h;
+
+    const int key = n0 + pair * 32 + r;
+    const bool kmem = key < p.Sk;   // memory-valid
+    const bool kval = key < kvl;    // participates in the softmax
+    bf16x8 Kh[HK], Vh[HK];
+#pragma unroll
+    for (int ks = 0; ks < HK; ++ks) {
+        Kh[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + (g * HK + ks) * 16 + 8 * h, kval);
+        Vh[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + (g * HK + ks) * 16 + 8 * h, kval);
+    }
+    f32x16 dK[HT], dV[HT];
+#pragma unroll
+    for (int dt = 0; dt < HT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dK[dt][i] = 0.f;
+            dV[dt][i] = 0.f;
+        }
+    const float sc = p.scale * kLog2e;
+
+    const int nqt = (p.Sq + BQ - 1) / BQ;
+    const int niter = (n0 < kvl) ? G * nqt : 0;   // fully masked key blocks get zero gradients
+    const int per_split = (niter + p.nsplit - 1) / p.nsplit;
+    const int it0 = split * per_split, it1 = min(niter, it0 + per_split);
+    typedef DmaTile<D, BQ> Stage;
+    const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s;
+    // this wave's share of tile `it`: Q, dO, and one 4-byte DMA — wave 0 brings the tile's 32 lse values, wave 1 its 32
+    // delta values, the other waves issue a filler into a dump slot so that EVERY wave has the same number of DMAs per
+    // tile (the counted vmcnt below relies on it).  Queries beyond Sq read 0 everywhere: a zero dO row contributes nothing.
+    auto stage = [&](int it, int buf) {
+        const int gq = it / nqt, t = it % nqt;
+        const int hq = hkv * G + gq;
+        const bf16_t* Qh_ = p.q + b * p.sq.b + hq * p.sq.h;
+        const bf16_t* dOh_ = p.dout + b * p.sdo.b + hq * p.sdo.h;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
+        char* base = smem + buf * BUFB;
+        Stage::issue(rq, base, t * BQ, p.Sq, qs_s);
+        Stage::issue(rdo, base + TILE, t * BQ, p.Sq, dos_s);
+        const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
+        char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
+        dma4(rs, sdst, (w < 2 && lane < 32) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+    };
+    if (it0 < it1) stage(it0, 0);
+    if (it0 + 1 < it1) stage(it0 + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind
+
+    // fragment addresses (bytes inside a 32-row tile): row reads: query row r, chunk 2 ks + h (ks in this wave's half);
+    // transposed reads: query rows 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
+    // (the half's first chunk c0 = g D/16: its low 4 bits take part in the swizzle's XOR, the rest is a plain offset)
+    const int c0 = g * (D / 16);
+    const int rbase = r * RB + ((h ^ swz_f(r) ^ (c0 & 15)) << 4) + (c0 & ~15) * 16;
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int tbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 4 * h + (i16 >> 2) + 8 * hi;
+        tbase[hi] = vr * RB + ((cc ^ swz_f(vr) ^ (c0 & 15)) << 4) + (i16 & 1) * 8 + (c0 & ~15) * 16;
+    }
+    float4* xa = reinterpret_cast<float4*>(smem + XA) + pair * 8 * 64 + lane;   // [e][lane]
+    u32x4* xb = reinterpret_cast<u32x4*>(smem + XB) + pair * 4 * 64 + lane;
+
+    int buf = 0;
+    for (int it = it0; it < it1; ++it) {
+        const char* Qs = smem + buf * BUFB;
+        const char* dOs = Qs + TILE;
+        const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE);
+        const float* dl_s = lse_s + 64;
+        // lane-constant addresses, made opaque per tile: hoisted out of the loop their XOR-ed variants (8 + 8 registers)
+        // would stay live across it, and this kernel has none to spare
+        int rb = rbase, tb0 = tbase[0], tb1 = tbase[1];
+        asm volatile("" : "+v"(rb), "+v"(tb0), "+v"(tb1));
+        // ---- phase A: partial S and dP over this wave's half of the head dimension ----
+        f32x16 S, dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            S[i] = 0.f;
+            dP[i] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < HK; ++ks) {
+            const int o = (rb ^ ((ks & 7) << 5)) + (ks >> 3) * 256;
+            S = mfma32(*reinterpret_cast<const bf16x8*>(Qs + o), Kh[ks], S);
+            dP = mfma32(*reinterpret_cast<const bf16x8*>(dOs + o), Vh[ks], dP);
+        }
+        if (!lead) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xa[e * 64] = make_float4(S[4 * e], S[4 * e + 1], S[4 * e + 2], S[4 * e + 3]);
+                xa[(4 + e) * 64] = make_float4(dP[4 * e], dP[4 * e + 1], dP[4 * e + 2], dP[4 * e + 3]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B1: tile it+2 on its way (its buffer was last read in phase B2 of tile it-1, which both groups have
+        //      left); the leader sums the partials and forms P, dS for the pair ----
+        const bool more2 = it + 2 < it1;
+        bf16x8 Pf[2], dSf[2];
+        if (lead) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 a = xa[g4 * 64], c = xa[(4 + g4) * 64];
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g4 + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 8 * g4 + 4 * h);
+                const float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float pv = __builtin_amdgcn_exp2f((S[4 * g4 + i] + av[i]) * sc - l4[i] * kLog2e);
+                    if (!kval) pv = 0.f;
+                    S[4 * g4 + i] = pv;
+                    dP[4 * g4 + i] = pv * (dP[4 * g4 + i] + cv[i] - d4[i]);
+                }
+            }
+            Pf[0] = pack8(S, 0);
+            Pf[1] = pack8(S, 1);
+            dSf[0] = pack8(dP, 0);
+            dSf[1] = pack8(dP, 1);
+            xb[0] = __builtin_bit_cast(u32x4, Pf[0]);
+            xb[64] = __builtin_bit_cast(u32x4, Pf[1]);
+            xb[128] = __builtin_bit_cast(u32x4, dSf[0]);
+            xb[192] = __builtin_bit_cast(u32x4, dSf[1]);
+        }
+        if (more2) stage(it + 2, buf == 0 ? 2 : buf - 1);
+        // this wave's share of tile it+1 (issued one tile ago) has landed: the group ahead reads it right after the
+        // barrier below; only the DMAs just issued for tile it+2 stay in flight
+        if (more2) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B2: dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS   (d in this wave's half) ----
+        if (!lead) {
+            Pf[0] = __builtin_bit_cast(bf16x8, xb[0]);
+            Pf[1] = __builtin_bit_cast(bf16x8, xb[64]);
+            dSf[0] = __builtin_bit_cast(bf16x8, xb[128]);
+            dSf[1] = __builtin_bit_cast(bf16x8, xb[192]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < HT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int o0 = kk * 16 * RB + (dt >> 2) * 256, x = (dt & 3) << 6;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dOs + o0 + (tb0 ^ x)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dOs + o0 + (tb1 ^ x)));
+                dV[dt] = mfma32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), Pf[kk], dV[dt]);
+                s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Qs + o0 + (tb0 ^ x)));
+                s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Qs + o0 + (tb1 ^ x)));
+                dK[dt] = mfma32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7)), dSf[kk], dK[dt]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // every wave executes the same number of barriers
+    const int dcol0 = g * (D / 2);
+    if (p.nsplit > 1) {
+        // fp32 partials, summed in a fixed order by attn_bwd_split_reduce_kernel (deterministic)
+        if (kmem) {
+            const int64_t plane = (int64_t)p.B * p.Hkv * p.Sk * D;
+            float* wk = p.split_ws + (((int64_t)split * p.B * p.Hkv + bh) * p.Sk + key) * D;
+            float* wv = wk + (int64_t)p.nsplit * plane;
+#pragma unroll
+            for (int dt = 0; dt < HT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = dcol0 + dt * 32 + 8 * e + 4 * h;
+                    f32x4 a, c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = dK[dt][4 * e + i];
+                        c[i] = dV[dt][4 * e + i];
+                    }
+                    *reinterpret_cast<f32x4*>(wk + d) = a;
+                    *reinterpret_cast<f32x4*>(wv + d) = c;
+                }
+        }
+        return;
+    }
+    if (kmem) {
+        const float s_ = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < HT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = dcol0 + dt * 32 + 8 * e + 4 * h;
+                store4(dKb + (int64_t)key * p.sdk.s + d, dK[dt][4 * e] * s_, dK[dt][4 * e + 1] * s_, dK[dt][4 * e + 2] * s_,
+                       dK[dt][4 * e + 3] * s_);
+                store4(dVb + (int64_t)key * p.sdv.s + d, dV[dt][4 * e], dV[dt][4 * e + 1], dV[dt][4 * e + 2], dV[dt][4 * e + 3]);
+            }
+    }
+}
+
+// =============================================================================================
+// backward dK/dV, head_dim >= 128, third form: 4 waves x 32 keys, the whole head dimension per wave, ONE wave per SIMD
+// with the full 512-register file — the accumulators (dK, dV: D registers) and the K / V fragments (D/2) leave room for
+// what the first-generation kernel lacked: fragment reads issued several steps ahead of the MFMAs that consume them.
+// (Measured on that kernel and on the 8-wave split above: every MFMA waited for its own ds_read, one read in flight per
+// wave, ~8 200 cycles per 32-query tile for 2 048 cycles of MFMA work, whatever the wave arrangement.)
+// Q / dO tiles (32 queries) arrive by LDS-DMA into the swizzled unpadded image of the forward kernel, in a ring of four
+// buffers filled three tiles ahead; tiles past the end are issued as all-out-of-range DMAs (zeros, no memory traffic) so
+// that the counted vmcnt is the same in every iteration.  One barrier per tile.
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, BQ = 32, NB = 4;
+    constexpr int TILE = BQ * RB;           // bytes of one Q (or dO) tile
+    constexpr int BUFB = 2 * TILE + 512;    // Q | dO | lse[32] (+128 B) | delta[32] (+128 B)
+    constexpr int DUMP = NB * BUFB;         // 256 B per wave for the filler DMAs of waves 2, 3
+    typedef DmaTile<D, BQ, 4> Stage;
+    constexpr int NDMA = 2 * Stage::NI + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ktile, bh;
+    if (!xcd_map(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv, ktile, bh)) return;  // block-uniform
+    const int split = ktile % p.nsplit;
+    ktile /= p.nsplit;
+    const int b = bh / p.Hkv, hkv = bh % p.Hkv, n0 = ktile * 128;
+    const int G = p.Hq / p.Hkv;
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dKb = p.dk + b * p.sdk.b + hkv * p.sdk.h;
+    bf16_t* dVb = p.dv + b * p.sdv.b + hkv * p.sdv.h;
+
+    const int key = n0 + w * 32 + r;
+    const bool kmem = key < p.Sk;   // memory-valid
+    const bool kval = key < kvl;    // participates in the softmax
+    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
+        Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
+    }
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dK[dt][i] = 0.f;
+            dV[dt][i] = 0.f;
+        }
+    const float sc = p.scale * kLog2e;
+
+    const int nqt = (p.Sq + BQ - 1) / BQ;
+    const int niter = (n0 < kvl) ? G * nqt : 0;   // fully masked key blocks get zero gradients
+    const int per_split = (niter + p.nsplit - 1) / p.nsplit;
+    const int it0 = split * per_split, it1 = min(niter, it0 + per_split);
+    const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s;
+    // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 32 lse
+    // values, wave 1 its 32 delta values, waves 2-3 a filler, so that every wave issues NDMA instructions per tile
+    auto stage = [&](int it, int buf) {
+        const bool live = it < it1;
+        const int itc = live ? it : it0;
+        const int gq = itc / nqt, t = itc % nqt;
+        const int hq = hkv * G + gq;
+        const bf16_t* Qh_ = p.q + b * p.sq.b + hq * p.sq.h;
+        const bf16_t* dOh_ = p.dout + b * p.sdo.b + hq * p.sdo.h;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
+        char* base = smem + buf * BUFB;
+        const int lim = live ? p.Sq : 0;
+        Stage::issue(rq, base, t * BQ, lim, qs_s);
+        Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
+        const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
+        char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
+        dma4(rs, sdst, (live && w < 2 && lane < 32) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+    };
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j) stage(it0 + j, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NDMA) : "memory");  // the first tile has landed
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses (bytes inside a 32-row tile): row reads: query row r, chunk 2 ks + h;
+    // transposed reads: query rows 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
+    const int rbase = r * RB + ((h ^ swz_f(r)) << 4);
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int tbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 4 * h + (i16 >> 2) + 8 * hi;
+        tbase[hi] = vr * RB + ((cc ^ swz_f(vr)) << 4) + (i16 & 1) * 8;
+    }
+    constexpr int PF = D >= 256 ? 3 : 4;  // row fragments in flight ahead of their MFMAs (what the register file affords)
+    constexpr int TF = D >= 256 ? 2 : 3;  // (d-tile, k-step) steps of transposed fragments in flight
+
+    int buf = 0;
+    for (int it = it0; it < it1; ++it) {
+        const char* Qs = smem + buf * BUFB;
+        const char* dOs = Qs + TILE;
+        const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE);
+        const float* dl_s = lse_s + 64;
+        stage(it + NB - 1, buf == 0 ? NB - 1 : buf - 1);  // the buffer tile it-1 has just left
+        auto rowoff = [&](int ks) { return (rbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256; };
+        // ---- S = Q K^T, dP = dO V^T: fragment reads run PF steps ahead ----
+        bf16x8 qa[PF], da[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            qa[j] = *reinterpret_cast<const bf16x8*>(Qs + rowoff(j));
+            da[j] = *reinterpret_cast<const bf16x8*>(dOs + rowoff(j));
+        }
+        f32x16 S, dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            S[i] = 0.f;
+            dP[i] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = qa[ks % PF], c = da[ks % PF];
+            if (ks + PF < KS) {
+                qa[ks % PF] = *reinterpret_cast<const bf16x8*>(Qs + rowoff(ks + PF));
+                da[ks % PF] = *reinterpret_cast<const bf16x8*>(dOs + rowoff(ks + PF));
+            }
+            S = mfma32(a, Kf[ks], S);
+            dP = mfma32(c, Vf[ks], dP);
+        }
+        // the first transposed fragments of the second half travel while the softmax runs on the VALU
+        auto trfrag = [&](const char* tile, int step) {  // step = dt * 2 + kk
+            const int dt = step >> 1, kk = step & 1;
+            const int o0 = kk * 16 * RB + (dt >> 2) * 256, x = (dt & 3) << 6;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0 + (tbase[0] ^ x)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0 + (tbase[1] ^ x)));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        bf16x8 ta[TF], tc[TF];
+#pragma unroll
+        for (int j = 0; j < TF; ++j) {
+            ta[j] = trfrag(dOs, j);
+            tc[j] = trfrag(Qs, j);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g4 + 4 * h);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
+                if (!kval) pv = 0.f;
+                S[4 * g4 + i] = pv;
+                dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+            }
+        }
+        bf16x8 Pf[2], dSf[2];
+        Pf[0] = pack8(S, 0);
+        Pf[1] = pack8(S, 1);
+        dSf[0] = pack8(dP, 0);
+        dSf[1] = pack8(dP, 1);
+        // ---- dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS ----
+#pragma unroll
+        for (int st = 0; st < 2 * DT; ++st) {
+            const bf16x8 a = ta[st % TF], c = tc[st % TF];
+            if (st + TF < 2 * DT) {
+                ta[st % TF] = trfrag(dOs, st + TF);
+                tc[st % TF] = trfrag(Qs, st + TF);
+            }
+            dV[st >> 1] = mfma32(a, Pf[st & 1], dV[st >> 1]);
+            dK[st >> 1] = mfma32(c, dSf[st & 1], dK[st >> 1]);
+        }
+        // this wave's share of tile it+1 has landed (issued three tiles ago); tiles it+2, it+3 stay in flight
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        buf = buf == NB - 1 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of ours may still write LDS when the workgroup ends
+    if (p.nsplit > 1) {
+        // fp32 partials, summed in a fixed order by attn_bwd_split_reduce_kernel (deterministic)
+        if (kmem) {
+            const int64_t plane = (int64_t)p.B * p.Hkv * p.Sk * D;
+            float* wk = p.split_ws + (((int64_t)split * p.B * p.Hkv + bh) * p.Sk + key) * D;
+            float* wv = wk + (int64_t)p.nsplit * plane;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = dt * 32 + 8 * e + 4 * h;
+                    f32x4 a, c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = dK[dt][4 * e + i];
+                        c[i] = dV[dt][4 * e + i];
+                    }
+                    *reinterpret_cast<f32x4*>(wk + d) = a;
+                    *reinterpret_cast<f32x4*>(wv + d) = c;
+                }
+        }
+        return;
+    }
+    if (kmem) {
+        const float s_ = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = dt * 32 + 8 * e + 4 * h;
+                store4(dKb + (int64_t)key * p.sdk.s + d, dK[dt][4 * e] * s_, dK[dt][4 * e + 1] * s_, dK[dt][4 * e + 2] * s_,
+                       dK[dt][4 * e + 3] * s_);
+                store4(dVb + (int64_t)key * p.sdv.s + d, dV[dt][4 * e], dV[dt][4 * e + 1], dV[dt][4 * e + 2], dV[dt][4 * e + 3]);
+            }
+    }
+}
+
 // dk / dv = Σ_split partial (fixed order), dk scaled; one thread = 4 consecutive d of one key
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_split_reduce_kernel(AttnParams p) {
@@ -770,9 +1612,37 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
     return 0;
 }
 
+template <int D>
+int launch_fwd2(const AttnParams& p, hipStream_t st) {
+    // two K/V buffers (they also carry the pair merge: 8 x D/4 float4 x 64 lanes = the same bytes) + the pair's m / l
+    constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t) + 8 * 64 * sizeof(float2);
+    static_assert(8 * (D / 64) * 4 * 64 * 16 <= 2 * 2 * 64 * D * 2, "merge area");
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid(xcd_grid((p.Sq + 127) / 128, p.B * p.Hq));
+    hipLaunchKernelGGL(attn_fwd2_kernel<D>, grid, dim3(512), lds, st, p);
+    VFT_CHECK_LAUNCH("vft_attn_fwd");
+    return 0;
+}
+
 template <int D, int BQ>
 int launch_bwd(const AttnParams& p, hipStream_t st) {
-    {
+    if (D >= 128 && g_attn_variant != 1) {
+        if constexpr (D >= 128) {
+            constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t);  // double-buffered K | V tiles, unpadded
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq3_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            dim3 grid(xcd_grid((p.Sq + 127) / 128, p.B * p.Hq));
+            hipLaunchKernelGGL(attn_bwd_dq3_kernel<D>, grid, dim3(256), lds, st, p);  // also writes delta
+            VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
+        }
+    } else {
         constexpr size_t lds = 2 * 2 * 64 * (D + 8) * sizeof(bf16_t);
         static bool attr = false;
         if (!attr) {
@@ -784,7 +1654,42 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);  // also writes delta
         VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
-    {
+    if (D >= 128 && g_attn_variant == 0) {
+        if constexpr (D >= 128) {
+            constexpr size_t lds = 4 * (2 * 32 * D * 2 + 512) + 4 * 256;  // four Q|dO|stats buffers + filler slots
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv3_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
+            hipLaunchKernelGGL((attn_bwd_dkdv3_kernel<D>), grid, dim3(256), lds, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
+        }
+        if (p.nsplit > 1) {
+            const int64_t n = (int64_t)p.B * p.Hkv * p.Sk * (D / 4);
+            hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(split reduce)");
+        }
+    } else if (D >= 128 && g_attn_variant == 2) {
+        if constexpr (D >= 128) {
+            // three Q|dO|stats buffers + the pairs' exchange slabs (partials, packed P/dS) + one dump slot per wave
+            constexpr size_t lds = 3 * (2 * 32 * D * 2 + 512) + 4 * 8 * 64 * 16 + 4 * 4 * 64 * 16 + 8 * 256;
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
+            hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<D>), grid, dim3(512), lds, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
+        }
+        if (p.nsplit > 1) {
+            const int64_t n = (int64_t)p.B * p.Hkv * p.Sk * (D / 4);
+            hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(split reduce)");
+        }
+    } else {
         constexpr size_t lds = 2 * (2 * BQ * (D + 8) * sizeof(bf16_t) + 2 * BQ * sizeof(float));  // double-buffered
         static bool attr = false;
         if (!attr) {
@@ -829,9 +1734,15 @@ extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* o
     switch (D) {
         case 64: return launch_fwd<64>(p, st);
         case 96: return launch_fwd<96>(p, st);
-        case 128: return launch_fwd<128>(p, st);
-        default: return launch_fwd<256>(p, st);
+        case 128: return g_attn_variant == 1 ? launch_fwd<128>(p, st) : launch_fwd2<128>(p, st);
+        default: return g_attn_variant == 1 ? launch_fwd<256>(p, st) : launch_fwd2<256>(p, st);
     }
+}
+
+extern "C" int vft_attn_variant(int variant) {
+    VFT_CHECK_ARG(variant >= 0 && variant <= 2, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels) or 2 (8-wave dK/dV)", variant);
+    g_attn_variant = variant;
+    return 0;
 }
 
 // floats the caller should allocate for vft_attn_bwd's workspace: delta, plus split-Q partials when they pay
