@@ -61,7 +61,7 @@ def attn():
         fl = 4.0 * B * H * Sq * Sk * D
         line = f"B={B} H={H}/{Hkv} Sq={Sq} Sk={Sk} D={D:3d}"
         outs = []
-        for var in ((1, 0) if D >= 128 else (0,)):
+        for var in ((1, 0) if D != 96 else (0,)):
             _C.lib().vft_attn_variant(var)
             o = kernels.flash_attention(q, k, v)
             outs.append(o.detach().float())

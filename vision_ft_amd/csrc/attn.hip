@@ -360,7 +360,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 16, voff, 0, 0, 0);
 }
-__device__ __forceinline__ int swz_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// (256-byte and longer rows: 16 chunks per bank window, f as above; 128-byte rows (head_dim 64): two rows share a bank window
+// and a row has 8 chunks: f(r) = (((r >> 1) & 1) << 2) | ((r >> 2) & 3) — the same two access patterns, conflict-free)
+template <int RB>
+__device__ __forceinline__ int swz_f(int row) {
+    static_assert(RB == 128 || RB % 256 == 0, "row size");
+    return RB == 128 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3));
+}
 
 // rows x (D*2)-byte tile by LDS-DMA, 512 threads: wave-instruction i covers 1024 bytes = 1024/(2D) rows.  Nothing is
 // kept per instruction: the lane's row and swizzled source chunk are recomputed at issue (a few VALU operations per
@@ -377,7 +383,7 @@ struct DmaTile {
         for (int q = 0; q < NI; ++q) {
             const int byte = (wv * NI + q) * 1024 + lane * 16;
             const int r = byte / RB, slot = (byte % RB) >> 4;
-            const int c = (slot & ~15) | ((slot & 15) ^ swz_f(r));
+            const int c = (slot & ~15) | ((slot & 15) ^ swz_f<RB>(r));
             const int voff = (row0 + r) * row_stride_elems * 2 + c * 16;
             dma16(rs, lds_tile + (wv * NI + q) * 1024, row0 + r < row_limit ? voff : OOBV);
         }
@@ -431,13 +437,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
     // fragment addresses of this lane (bytes inside a tile).  K rows: row 32 g + r, chunk 2 ks + h;
     // V transposed: rows 32 g + 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
     const int krow = 32 * g + r;
-    const int kbase = krow * RB + ((h ^ swz_f(krow)) << 4);  // ^ ((ks & 7) << 5), + (ks >> 3) * 256
+    const int kbase = krow * RB + ((h ^ swz_f<RB>(krow)) << 4);  // ^ ((ks & 7) << 5), + (ks >> 3) * 256
     const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     int vbase[2];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
         const int vr = 32 * g + 4 * h + (i16 >> 2) + 8 * hi;
-        vbase[hi] = vr * RB + ((cc ^ swz_f(vr)) << 4) + (i16 & 1) * 8;  // ^ ((dt & 3) << 6), + (dt >> 2) * 256, + kk * 16 * RB
+        vbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;  // ^ ((dt & 3) << 6), + (dt >> 2) * 256, + kk * 16 * RB
     }
 
     for (int t = 0; t < ntiles; ++t) {
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 // steps ahead of the S / dP MFMAs, the transposed K fragments TF steps ahead of the dQ MFMAs.
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq3_kernel(AttnParams p) {
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;
     typedef DmaTile<D, 64, 4> Stage;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -769,13 +775,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(AttnParams p) {
 
     // fragment addresses (bytes inside a 64-row tile): row reads: key row 32 kt + r, chunk 2 ks + h; transposed reads:
     // key rows 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
-    const int rbase = r * RB + ((h ^ swz_f(r)) << 4);
+    const int rbase = r * RB + ((h ^ swz_f<RB>(r)) << 4);
     const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     int tbase[2];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
         const int vr = 4 * h + (i16 >> 2) + 8 * hi;
-        tbase[hi] = vr * RB + ((cc ^ swz_f(vr)) << 4) + (i16 & 1) * 8;
+        tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;
     }
     constexpr int PF = 4, TF = 4;
 
@@ -1159,13 +1165,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
     // transposed reads: query rows 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
     // (the half's first chunk c0 = g D/16: its low 4 bits take part in the swizzle's XOR, the rest is a plain offset)
     const int c0 = g * (D / 16);
-    const int rbase = r * RB + ((h ^ swz_f(r) ^ (c0 & 15)) << 4) + (c0 & ~15) * 16;
+    const int rbase = r * RB + ((h ^ swz_f<RB>(r) ^ (c0 & 15)) << 4) + (c0 & ~15) * 16;
     const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     int tbase[2];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
         const int vr = 4 * h + (i16 >> 2) + 8 * hi;
-        tbase[hi] = vr * RB + ((cc ^ swz_f(vr) ^ (c0 & 15)) << 4) + (i16 & 1) * 8 + (c0 & ~15) * 16;
+        tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr) ^ (c0 & 15)) << 4) + (i16 & 1) * 8 + (c0 & ~15) * 16;
     }
     float4* xa = reinterpret_cast<float4*>(smem + XA) + pair * 8 * 64 + lane;   // [e][lane]
     u32x4* xb = reinterpret_cast<u32x4*>(smem + XB) + pair * 4 * 64 + lane;
@@ -1311,11 +1317,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
 // buffers filled three tiles ahead; tiles past the end are issued as all-out-of-range DMAs (zeros, no memory traffic) so
 // that the counted vmcnt is the same in every iteration.  One barrier per tile.
 // =============================================================================================
-template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(AttnParams p) {
-    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, BQ = 32, NB = 4;
+template <int D, int BQ>
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, NB = 4, QT = BQ / 32;
+    static_assert(BQ == 32 || BQ == 64, "query tile");
     constexpr int TILE = BQ * RB;           // bytes of one Q (or dO) tile
-    constexpr int BUFB = 2 * TILE + 512;    // Q | dO | lse[32] (+128 B) | delta[32] (+128 B)
+    constexpr int BUFB = 2 * TILE + 512;    // Q | dO | lse[BQ] | delta[BQ]  (256-byte slots: one 4-byte DMA each)
     constexpr int DUMP = NB * BUFB;         // 256 B per wave for the filler DMAs of waves 2, 3
     typedef DmaTile<D, BQ, 4> Stage;
     constexpr int NDMA = 2 * Stage::NI + 1;
@@ -1360,8 +1367,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(AttnParams p) {
     const int per_split = (niter + p.nsplit - 1) / p.nsplit;
     const int it0 = split * per_split, it1 = min(niter, it0 + per_split);
     const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s;
-    // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 32 lse
-    // values, wave 1 its 32 delta values, waves 2-3 a filler, so that every wave issues NDMA instructions per tile
+    // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's BQ lse
+    // values, wave 1 its delta values, waves 2-3 a filler, so that every wave issues NDMA instructions per tile
     auto stage = [&](int it, int buf) {
         const bool live = it < it1;
         const int itc = live ? it : it0;
@@ -1378,7 +1385,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(AttnParams p) {
         const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
-        dma4(rs, sdst, (live && w < 2 && lane < 32) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        dma4(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
     };
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) stage(it0 + j, j);
@@ -1387,16 +1394,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(AttnParams p) {
 
     // fragment addresses (bytes inside a 32-row tile): row reads: query row r, chunk 2 ks + h;
     // transposed reads: query rows 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
-    const int rbase = r * RB + ((h ^ swz_f(r)) << 4);
+    const int rbase = r * RB + ((h ^ swz_f<RB>(r)) << 4);
     const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     int tbase[2];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi) {
         const int vr = 4 * h + (i16 >> 2) + 8 * hi;
-        tbase[hi] = vr * RB + ((cc ^ swz_f(vr)) << 4) + (i16 & 1) * 8;
+        tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;
     }
-    constexpr int PF = D >= 256 ? 3 : 4;  // row fragments in flight ahead of their MFMAs (what the register file affords)
-    constexpr int TF = D >= 256 ? 2 : 3;  // (d-tile, k-step) steps of transposed fragments in flight
+    constexpr int PF = D >= 256 ? 3 : 4;                     // row fragments in flight ahead of their MFMAs (what the register file affords)
+    constexpr int TF = D >= 256 ? 2 : (2 * DT < 3 ? 2 * DT : 3);  // (d-tile, k-step) steps of transposed fragments in flight
+    static_assert(PF <= KS && TF <= 2 * DT, "ring depth");
 
     int buf = 0;
     for (int it = it0; it < it1; ++it) {
@@ -1406,70 +1414,75 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv3_kernel(AttnParams p) {
         const float* dl_s = lse_s + 64;
         stage(it + NB - 1, buf == 0 ? NB - 1 : buf - 1);  // the buffer tile it-1 has just left
         auto rowoff = [&](int ks) { return (rbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256; };
-        // ---- S = Q K^T, dP = dO V^T: fragment reads run PF steps ahead ----
-        bf16x8 qa[PF], da[PF];
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            qa[j] = *reinterpret_cast<const bf16x8*>(Qs + rowoff(j));
-            da[j] = *reinterpret_cast<const bf16x8*>(dOs + rowoff(j));
-        }
-        f32x16 S, dP;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            S[i] = 0.f;
-            dP[i] = 0.f;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a = qa[ks % PF], c = da[ks % PF];
-            if (ks + PF < KS) {
-                qa[ks % PF] = *reinterpret_cast<const bf16x8*>(Qs + rowoff(ks + PF));
-                da[ks % PF] = *reinterpret_cast<const bf16x8*>(dOs + rowoff(ks + PF));
-            }
-            S = mfma32(a, Kf[ks], S);
-            dP = mfma32(c, Vf[ks], dP);
-        }
-        // the first transposed fragments of the second half travel while the softmax runs on the VALU
-        auto trfrag = [&](const char* tile, int step) {  // step = dt * 2 + kk
+        auto trfrag = [&](const char* tile, int step) {  // step = dt * 2 + kk; tile = the sub-tile's first row
             const int dt = step >> 1, kk = step & 1;
             const int o0 = kk * 16 * RB + (dt >> 2) * 256, x = (dt & 3) << 6;
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0 + (tbase[0] ^ x)));
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0 + (tbase[1] ^ x)));
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
-        bf16x8 ta[TF], tc[TF];
 #pragma unroll
-        for (int j = 0; j < TF; ++j) {
-            ta[j] = trfrag(dOs, j);
-            tc[j] = trfrag(Qs, j);
-        }
+        for (int qt = 0; qt < QT; ++qt) {
+            const char* Qq = Qs + qt * 32 * RB;
+            const char* dOq = dOs + qt * 32 * RB;
+            // ---- S = Q K^T, dP = dO V^T: fragment reads run PF steps ahead ----
+            bf16x8 qa[PF], da[PF];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g4 + 4 * h);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 8 * g4 + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
-                if (!kval) pv = 0.f;
-                S[4 * g4 + i] = pv;
-                dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+            for (int j = 0; j < PF; ++j) {
+                qa[j] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(j));
+                da[j] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(j));
             }
-        }
-        bf16x8 Pf[2], dSf[2];
-        Pf[0] = pack8(S, 0);
-        Pf[1] = pack8(S, 1);
-        dSf[0] = pack8(dP, 0);
-        dSf[1] = pack8(dP, 1);
-        // ---- dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS ----
+            f32x16 S, dP;
 #pragma unroll
-        for (int st = 0; st < 2 * DT; ++st) {
-            const bf16x8 a = ta[st % TF], c = tc[st % TF];
-            if (st + TF < 2 * DT) {
-                ta[st % TF] = trfrag(dOs, st + TF);
-                tc[st % TF] = trfrag(Qs, st + TF);
+            for (int i = 0; i < 16; ++i) {
+                S[i] = 0.f;
+                dP[i] = 0.f;
             }
-            dV[st >> 1] = mfma32(a, Pf[st & 1], dV[st >> 1]);
-            dK[st >> 1] = mfma32(c, dSf[st & 1], dK[st >> 1]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = qa[ks % PF], c = da[ks % PF];
+                if (ks + PF < KS) {
+                    qa[ks % PF] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(ks + PF));
+                    da[ks % PF] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(ks + PF));
+                }
+                S = mfma32(a, Kf[ks], S);
+                dP = mfma32(c, Vf[ks], dP);
+            }
+            // the first transposed fragments of the second half travel while the softmax runs on the VALU
+            bf16x8 ta[TF], tc[TF];
+#pragma unroll
+            for (int j = 0; j < TF; ++j) {
+                ta[j] = trfrag(dOq, j);
+                tc[j] = trfrag(Qq, j);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
+                    if (!kval) pv = 0.f;
+                    S[4 * g4 + i] = pv;
+                    dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                }
+            }
+            bf16x8 Pf[2], dSf[2];
+            Pf[0] = pack8(S, 0);
+            Pf[1] = pack8(S, 1);
+            dSf[0] = pack8(dP, 0);
+            dSf[1] = pack8(dP, 1);
+            // ---- dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS ----
+#pragma unroll
+            for (int st = 0; st < 2 * DT; ++st) {
+                const bf16x8 a = ta[st % TF], c = tc[st % TF];
+                if (st + TF < 2 * DT) {
+                    ta[st % TF] = trfrag(dOq, st + TF);
+                    tc[st % TF] = trfrag(Qq, st + TF);
+                }
+                dV[st >> 1] = mfma32(a, Pf[st & 1], dV[st >> 1]);
+                dK[st >> 1] = mfma32(c, dSf[st & 1], dK[st >> 1]);
+            }
         }
         // this wave's share of tile it+1 has landed (issued three tiles ago); tiles it+2, it+3 stay in flight
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * NDMA) : "memory");
@@ -1630,8 +1643,8 @@ int launch_fwd2(const AttnParams& p, hipStream_t st) {
 
 template <int D, int BQ>
 int launch_bwd(const AttnParams& p, hipStream_t st) {
-    if (D >= 128 && g_attn_variant != 1) {
-        if constexpr (D >= 128) {
+    if (D != 96 && g_attn_variant != 1) {
+        if constexpr (D != 96) {
             constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t);  // double-buffered K | V tiles, unpadded
             static bool attr = false;
             if (!attr) {
@@ -1654,16 +1667,17 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);  // also writes delta
         VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
-    if (D >= 128 && g_attn_variant == 0) {
-        if constexpr (D >= 128) {
-            constexpr size_t lds = 4 * (2 * 32 * D * 2 + 512) + 4 * 256;  // four Q|dO|stats buffers + filler slots
+    if (D != 96 && g_attn_variant == 0) {
+        if constexpr (D != 96) {
+            constexpr int BQ3 = D <= 64 ? 64 : 32;
+            constexpr size_t lds = 4 * (2 * BQ3 * D * 2 + 512) + 4 * 256;  // four Q|dO|stats buffers + filler slots
             static bool attr = false;
             if (!attr) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv3_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv3_kernel<D, BQ3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr = true;
             }
             dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
-            hipLaunchKernelGGL((attn_bwd_dkdv3_kernel<D>), grid, dim3(256), lds, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkdv3_kernel<D, BQ3>), grid, dim3(256), lds, st, p);
             VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
         }
         if (p.nsplit > 1) {
