@@ -30,6 +30,19 @@ torch.cuda.synchronize()
 print("algorithmic bytes: attn_fwd q+k+v+o =", 4 * B * H * S * D * 2, " lora_fwd =", 2 * M * K + 4 * M * N,
       " lora_bwd_dx =", 2 * M * N + 4 * M * K, " lora_wgrad2 =", 2 * M * (K + N))
 
+# the projection GEMM (lin8) at the SDXL headline shapes, per-GPU batch 24: the 64x64-latent FeedForward up-projection
+# (tokens 98304, 640 -> 5120, rank-4 extension + bias) and the 32x32-latent one (tokens 24576, 1280 -> 10240)
+import torch.nn.functional as F  # noqa: E402,F401
+
+for (M2, N2, K2) in [(98304, 5120, 640), (24576, 10240, 1280)]:
+    x2, w2, b2 = bf(M2, K2), bf(N2, K2) * 0.05, bf(N2)
+    t2, B2 = bf(M2, 4), bf(N2, 4)
+    for _ in range(3):
+        kernels.linear_fused(x2, w2, b2, ext_x=t2, ext_w=B2)
+    torch.cuda.synchronize()
+    print(f"lin8 {M2}x{N2}x{K2} algorithmic bytes (x + w + y + ext) =", 2 * (M2 * K2 + N2 * K2 + M2 * N2 + 4 * (M2 + N2)))
+    del x2, w2, b2, t2, B2
+
 # implicit-GEMM convolution (SDXL 320->320 at 128x128, B=16) forward + data gradient
 Bc, Ci, Co, Hc = 24, 320, 320, 128
 xc = bf(Bc, Ci, Hc, Hc).contiguous(memory_format=torch.channels_last).requires_grad_(True)

@@ -15,17 +15,32 @@ ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
     "lora_rows_kernelILi4ELb0": (2 * 98304 * 5120 + 4 * 98304 * 640) / 1e6,
     "lora_wgrad_partial": 2 * 98304 * (640 + 5120) / 1e6,
     "linear_kernel": (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6,
+    # round 2: the second-generation GEMM.  Its two plain instantiations are told apart by launch order in tools/pmc_run.py
+    # (first shape 98304 x 5120 x 640, then 24576 x 10240 x 1280: both pick the 256x256 tile); conv mode = C8<..., true>
+    "lin8_kernel": None,
 }
+LIN8_SHAPES = [("lin8_kernel", "M=98304 N=5120 K=640 (+bias, rank-4 extension)", 2 * (98304 * 640 + 5120 * 640 + 98304 * 5120 + 4 * (98304 + 5120)) / 1e6),
+               ("lin8_kernel_b", "M=24576 N=10240 K=1280 (+bias, rank-4 extension)", 2 * (24576 * 1280 + 10240 * 1280 + 24576 * 10240 + 4 * (24576 + 10240)) / 1e6),
+               ("lin8_conv", "conv3x3 320->320 @128x128, B=24", (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6)]
 
 
 def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc, n = collections.Counter(), collections.Counter()
+    lin8_seen = 0
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
+        name = r["Kernel_Name"]
+        if "lin8_kernel" in name:  # plain launches: 3 of the first shape, then 3 of the second; conv launches: Lb1 in the template
+            conv = "ELb1EE" in name
+            key = "lin8_conv" if conv else ("lin8_kernel" if lin8_seen < 3 else "lin8_kernel_b")
+            lin8_seen += 0 if conv else 1
+            acc[key] += float(r["Counter_Value"])
+            n[key] += 1
+            continue
         for k in ALG_MB:
-            if k in r["Kernel_Name"]:
+            if k in name:
                 acc[k] += float(r["Counter_Value"])
                 n[k] += 1
     return {k: acc[k] / n[k] for k in acc}, n
@@ -34,14 +49,18 @@ def per_kernel(d, counter):
 def main():
     fetch, n = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+    alg = {k: v for k, v in ALG_MB.items() if v is not None}
+    shape = {}
+    for k, sh, mb in LIN8_SHAPES:
+        alg[k], shape[k] = mb, sh
     with open(sys.argv[3], "w") as out:
-        out.write("kernel,launches,FETCH_SIZE_raw_KB_per_launch,fetch_MB_corrected_x2,write_MB,traffic_MB,algorithmic_MB\n")
-        for k in ALG_MB:
+        out.write("kernel,launches,FETCH_SIZE_raw_KB_per_launch,fetch_MB_corrected_x2,write_MB,traffic_MB,algorithmic_MB,shape\n")
+        for k in alg:
             if k not in fetch:
                 continue
             fmb = fetch[k] * 1024 * 2 / 1e6
             wmb = write.get(k, 0.0) * 1024 / 1e6
-            out.write(f"{k},{n[k]},{fetch[k]:.0f},{fmb:.1f},{wmb:.1f},{fmb + wmb:.1f},{ALG_MB[k]:.1f}\n")
+            out.write(f"{k},{n[k]},{fetch[k]:.0f},{fmb:.1f},{wmb:.1f},{fmb + wmb:.1f},{alg[k]:.1f},{shape.get(k, 'see tools/pmc_run.py')}\n")
     print(open(sys.argv[3]).read())
 
 

@@ -40,8 +40,10 @@ def main():
             return "gemm(hipblaslt)"
         if "igemm" in n or "Im2d2Col" in n or "Col2Im" in n or "SubTensorOp" in n or "transpose" in n.lower() or "ck::" in n or "naive_conv" in n:
             return "conv(miopen/ck)"
+        if "lin8_kernel" in n:
+            return "conv3x3(ours, lin8)" if "ELb1EE" in n or ", true>" in n else "linear gemm(ours, lin8)"
         if "linear_kernel" in n:
-            return "conv3x3/linear(ours)"
+            return "conv3x3/linear(ours, gen 1)"
         if "attn_" in n:
             return "attention(ours)"
         if "geglu" in n:
