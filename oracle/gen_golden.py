@@ -282,6 +282,91 @@ def gen_sdxl_rect():
              sizes=dict(original_size=[[192, 128], [300, 210]], target_size=[[192, 128], [192, 128]], crop=[[0, 0], [0, 24]]))
 
 
+def gen_sdxl_rope():
+    """SDXL with the 2-D RoPE attention adapter trained with the flow-matching objective:
+    reference `DenoiserWithRoPE` (src/models/sdxl/adapter/rope.py) on a non-square latent, origin "center" pushed into
+    the embedders the way `SDXLWithRoPEModel.apply_rope_config` does, and the step of train/sdxl/flow_match.py:109-174
+    (`prepare_scaled_noised_latents`, timestep * 1000 into the denoiser, velocity loss; plus the image-prediction
+    branch of `treat_loss`).  The adapter module imports `..pipeline` (VAE -> diffusers, absent here) only for the
+    model-holder class, so that one name is stubbed."""
+    cfgm = importlib.import_module("src.models.sdxl.config")
+    importlib.import_module("src.models.sdxl.denoiser")
+    pipe = types.ModuleType("src.models.sdxl.pipeline")
+    pipe.SDXLModel = type("SDXLModel", (torch.nn.Module,), {})
+    sys.modules["src.models.sdxl.pipeline"] = pipe
+    rope = importlib.import_module("src.models.sdxl.adapter.rope")
+    from src.modules.loss import flow_match as FM
+
+    hw = (16, 24)
+    cfg = rope.DenoiserConfigWithRoPE(**TINY_SDXL)  # rope_dims [32, 32], theta 1e4, origin "center"
+    model = rope.DenoiserWithRoPE(cfg)
+    for m in model.modules():  # SDXLWithRoPEModel.apply_rope_config, rope.py:553-560
+        if isinstance(m, rope.RoPEEmbedder):
+            m.rope_dims, m.rope_theta, m.origin_position = cfg.rope_dims, cfg.rope_theta, cfg.origin_position
+    model.train()
+    cs = load_synth(model, seed=0)
+    g = torch.Generator().manual_seed(77)
+    B = 2
+    T = {
+        "latents": torch.randn(B, 4, *hw, generator=g),
+        "t": torch.tensor([0.183, 0.764], dtype=torch.float32),  # sample_timestep output, 0..1
+        "ehs": torch.randn(B, 11, 64, generator=g),
+        "pooled": torch.randn(B, 1280, generator=g),
+        "original_size": torch.tensor([[128, 192], [200, 260]]),
+        "target_size": torch.tensor([[128, 192], [128, 192]]),
+        "crop": torch.tensor([[0, 0], [8, 16]]),
+    }
+    torch.manual_seed(123)
+    noisy, noise = FM.prepare_scaled_noised_latents(T["latents"], T["t"], noise_scale=1.0, clean_at_zero=False)
+    T["noisy"], T["noise"] = noisy, noise
+    torch.manual_seed(123)
+    T["noisy_c0"] = FM.prepare_scaled_noised_latents(T["latents"], T["t"], noise_scale=1.0, clean_at_zero=True)[0]
+    emb = next(m for m in model.modules() if isinstance(m, rope.RoPEEmbedder))
+    T["freqs.image"] = torch.view_as_real(emb.get_image_freqs(1, hw[0], hw[1], torch.device("cpu"))[0])
+    T["freqs.context"] = torch.view_as_real(emb.get_context_freqs(1, 11, torch.device("cpu"))[0])
+    T["ids.image"] = emb.get_image_position_ids(1, hw[0], hw[1])[0]
+    tl = rope.RoPEEmbedder([32, 32], origin_position="top_left")
+    T["ids.image_top_left"] = tl.get_image_position_ids(1, 5, 7)[0]
+    qk = torch.randn(2, 2, hw[0] * hw[1], 64, generator=g)
+    T["apply.in"] = qk
+    T["apply.out"] = rope.apply_rope(qk, emb.get_image_freqs(2, hw[0], hw[1], torch.device("cpu")))
+
+    def call(m, x=None):
+        return m(latents=T["noisy"] if x is None else x, timestep=T["t"] * 1000, encoder_hidden_states=T["ehs"],
+                 encoder_pooler_output=T["pooled"], original_size=T["original_size"],
+                 target_size=T["target_size"], crop_coords_top_left=T["crop"])
+
+    model.requires_grad_(True)
+    x = T["noisy"].clone().requires_grad_(True)
+    with autocast():
+        out = call(model, x)
+        loss = FM.loss_with_predicted_velocity(T["latents"], T["noise"], out)
+        # treat_loss, model_prediction "image" / loss_type "velocity" (flow_match.py:68-87)
+        v_t = FM.convert_x0_to_velocity(T["latents"], T["noisy"], T["t"], eps=1e-5, clean_at_zero=False)
+        v_p = FM.convert_x0_to_velocity(out, T["noisy"], T["t"], eps=1e-5, clean_at_zero=False)
+        loss_img = torch.nn.functional.mse_loss(v_p, v_t, reduction="mean")
+    loss.backward()
+    T["out"], T["loss"], T["loss_image_pred"], T["d_noisy"] = out.detach().float(), loss.detach().float(), loss_img.detach().float(), x.grad
+    T["x0_velocity_target"] = v_t.detach().float()
+    for name in ("out.2.weight", "middle_block.blocks.1.transformer_blocks.0.attn1.to_q.weight",
+                 "middle_block.blocks.1.transformer_blocks.0.attn2.to_k.weight",
+                 "output_blocks.blocks.1.1.transformer_blocks.0.attn1.to_k.weight"):
+        T["grad." + name] = dict(model.named_parameters())[name].grad
+    model.zero_grad()
+    with torch.no_grad(), autocast():  # rope switched off = the plain denoiser (set_rope_enabled, rope.py:472-478)
+        model.set_rope_enabled(False)
+        T["out_rope_off"] = call(model).float()
+        model.set_rope_enabled(True)
+    losses, keys = lora_train_steps(model, call, ["attn1", "attn2", ".ff."], 4,
+                                    lambda o: FM.loss_with_predicted_velocity(T["latents"], T["noise"], o))
+    T["lora.losses"] = losses
+    meta = {"config": json.dumps(TINY_SDXL), "checksum": repr(cs), "lora_keys": json.dumps(keys),
+            "rope": json.dumps(dict(rope_dims=cfg.rope_dims, rope_theta=cfg.rope_theta, origin_position=cfg.origin_position))}
+    save_file(t2c(T), os.path.join(OUT, "sdxl_rope_tiny.safetensors"), metadata=meta)
+    print("sdxl_rope_tiny loss", float(T["loss"]), "image-pred loss", float(T["loss_image_pred"]), "lora losses", losses.tolist(),
+          "rope on/off output distance", float((T["out"] - T["out_rope_off"]).norm() / T["out_rope_off"].norm()))
+
+
 def gen_aura():
     cfgm = importlib.import_module("src.models.auraflow.config")
     den = importlib.import_module("src.models.auraflow.denoiser")
@@ -712,8 +797,8 @@ def gen_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     import_reference()
-    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "aura", "lumina", "samplers", "checkpoint_keys"]
+    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "sdxl_rope", "aura", "lumina", "samplers", "checkpoint_keys"]
     torch.set_num_threads(8)
     for w in which:
-        {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "sdxl_rect": gen_sdxl_rect, "aura": gen_aura, "lumina": gen_lumina,
+        {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "sdxl_rect": gen_sdxl_rect, "sdxl_rope": gen_sdxl_rope, "aura": gen_aura, "lumina": gen_lumina,
          "samplers": gen_samplers, "checkpoint_keys": gen_checkpoint_keys}[w]()

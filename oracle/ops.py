@@ -105,6 +105,40 @@ def lumina_apply_rope(x_in: torch.Tensor, freqs_cis: torch.Tensor) -> torch.Tens
     return out.type_as(x_in)
 
 
+# SDXL 2-D RoPE adapter, src/models/sdxl/adapter/rope.py
+def sdxl_image_position_ids(height: int, width: int, origin_position: str = "top_left") -> torch.Tensor:
+    """rope.py:78-115 — (H*W, 2) int64 (y, x); "center" subtracts ceil(h // 2) / ceil(w // 2) (sic)."""
+    import math
+    y = torch.arange(height, dtype=torch.int64).view(-1, 1).repeat(1, width)
+    x = torch.arange(width, dtype=torch.int64).view(1, -1).repeat(height, 1)
+    if origin_position == "center":
+        y = y - math.ceil(height // 2)
+        x = x - math.ceil(width // 2)
+    return torch.stack([y, x], dim=-1).view(height * width, 2)
+
+
+def sdxl_context_position_ids(length: int) -> torch.Tensor:
+    """rope.py:117-126 — (i, i)"""
+    return torch.arange(length, dtype=torch.int64).view(-1, 1).repeat(1, 2)
+
+
+def sdxl_rope_freqs(position_ids: torch.Tensor, rope_dims: list[int], theta: float = 10000.0) -> torch.Tensor:
+    """rope.py:21-38 and :128-139 — per axis: float64 theta, fp32 radians, unit-modulus complex64; axes concatenated."""
+    parts = []
+    for ids, dim in zip(position_ids.chunk(2, dim=-1), rope_dims, strict=True):
+        assert dim % 2 == 0
+        exponent = torch.arange(0, dim, 2, dtype=torch.float64) / dim
+        radians = (ids * (1.0 / (theta**exponent))).float()
+        parts.append(torch.polar(torch.ones_like(radians), radians).to(torch.complex64))
+    return torch.cat(parts, dim=-1)
+
+
+def sdxl_apply_rope(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """rope.py:41-54 — x (B,H,S,D), freqs complex (S,D/2): complex multiply of interleaved pairs in fp32, cast back."""
+    xc = torch.view_as_complex(x.float().reshape(*x.shape[:-1], -1, 2))
+    return torch.view_as_real(xc * freqs.view(1, 1, *freqs.shape)).flatten(3).to(x.dtype)
+
+
 # ------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------
@@ -148,6 +182,19 @@ def flow_noise(latents: torch.Tensor, timestep: torch.Tensor, noise: torch.Tenso
 def flow_loss(latents: torch.Tensor, noise: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
     """modules/loss/flow_match.py:85-96"""
     return F.mse_loss(pred, noise - latents, reduction="mean")
+
+
+def flow_scaled_noise(latents: torch.Tensor, timestep: torch.Tensor, noise: torch.Tensor, clean_at_zero: bool = False) -> torch.Tensor:
+    """modules/loss/flow_match.py:60-74 with the (already scaled) noise passed in: t x + (1-t) eps, or the
+    clean-at-zero orientation (1-t) x + t eps."""
+    t = timestep.view([latents.size(0), *([1] * (latents.dim() - 1))])
+    return (1 - t) * latents + t * noise if clean_at_zero else t * latents + (1 - t) * noise
+
+
+def x0_to_velocity(x0: torch.Tensor, noisy: torch.Tensor, timestep: torch.Tensor, eps: float = 1e-5, clean_at_zero: bool = False):
+    """modules/loss/flow_match.py:102-116"""
+    t = timestep.view([x0.size(0), *([1] * (x0.dim() - 1))])
+    return (noisy - x0) / t.clamp_min(eps) if clean_at_zero else (x0 - noisy) / (1 - t).clamp_min(eps)
 
 
 # ------------------------------------------------------------------------------------------

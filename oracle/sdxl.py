@@ -37,8 +37,9 @@ class SDXLCfg:
     up_blocks: list = field(default_factory=lambda: ["TransformerUpBlock2D", "TransformerUpBlock2D", "UpBlock2D"])
 
 
-def _attention(P, pre, x, ctx, heads, head_dim):
-    """SelfAttention / CrossAttention forward, denoiser.py:57-94 and :135-172."""
+def _attention(P, pre, x, ctx, heads, head_dim, fq=None, fk=None):
+    """SelfAttention / CrossAttention forward, denoiser.py:57-94 and :135-172; with `fq`/`fk` (complex RoPE tables for
+    the query / key positions) the *WithRoPE variants of adapter/rope.py:196-316."""
     q = ops.linear(P, f"{pre}.to_q", x)
     k = ops.linear(P, f"{pre}.to_k", ctx)
     v = ops.linear(P, f"{pre}.to_v", ctx)
@@ -47,34 +48,43 @@ def _attention(P, pre, x, ctx, heads, head_dim):
     q = q.reshape(b, s, heads, head_dim).permute(0, 2, 1, 3)
     k = k.reshape(b, sk, heads, head_dim).permute(0, 2, 1, 3)
     v = v.reshape(b, sk, heads, head_dim).permute(0, 2, 1, 3)
+    if fq is not None:
+        q = ops.sdxl_apply_rope(q, fq)
+        k = ops.sdxl_apply_rope(k, fk)
     a = sdpa(q, k, v)
     a = a.permute(0, 2, 1, 3).reshape(b, s, heads * head_dim)
     return ops.linear(P, f"{pre}.to_out.0", a)
 
 
-def _transformer_block(P, pre, x, ctx, heads, head_dim):
-    """TransformerBlock.forward, denoiser.py:254-280; GEGLU FF :183-204."""
+def _transformer_block(P, pre, x, ctx, heads, head_dim, f_img=None, f_ctx=None):
+    """TransformerBlock.forward, denoiser.py:254-280; GEGLU FF :183-204.  TransformerWithRoPE (adapter/rope.py:398-447)
+    rotates attn1's q,k by the image table and attn2's q / k by the image / context tables."""
     c = x.shape[-1]
     h = F.layer_norm(x, (c,), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"])
-    x = x + _attention(P, f"{pre}.attn1", h, h, heads, head_dim)
+    x = x + _attention(P, f"{pre}.attn1", h, h, heads, head_dim, f_img, f_img)
     h = F.layer_norm(x, (c,), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"])
-    x = x + _attention(P, f"{pre}.attn2", h, ctx, heads, head_dim)
+    x = x + _attention(P, f"{pre}.attn2", h, ctx, heads, head_dim, f_img, f_ctx)
     h = F.layer_norm(x, (c,), P[f"{pre}.norm3.weight"], P[f"{pre}.norm3.bias"])
     hs, gate = ops.linear(P, f"{pre}.ff.net.0.proj", h).chunk(2, dim=-1)
     x = x + ops.linear(P, f"{pre}.ff.net.2", hs * F.gelu(gate))
     return x
 
 
-def _spatial_transformer(P, pre, x, ctx, head_dim, n_blocks):
-    """SpatialTransformer.forward, denoiser.py:320-365 (GN eps 1e-6, NCHW<->NLC)."""
+def _spatial_transformer(P, pre, x, ctx, head_dim, n_blocks, rope=None):
+    """SpatialTransformer.forward, denoiser.py:320-365 (GN eps 1e-6, NCHW<->NLC); it hands (height, width) to its
+    blocks (:342-346), from which the RoPE blocks build their tables."""
     b, c, hh, ww = x.shape
     heads = c // head_dim
+    f_img = f_ctx = None
+    if rope is not None:
+        f_img = ops.sdxl_rope_freqs(ops.sdxl_image_position_ids(hh, ww, rope["origin_position"]), rope["rope_dims"], rope["rope_theta"])
+        f_ctx = ops.sdxl_rope_freqs(ops.sdxl_context_position_ids(ctx.shape[1]), rope["rope_dims"], rope["rope_theta"])
     res = x
     h = F.group_norm(x, 32, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], eps=1e-6)
     h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
     h = ops.linear(P, f"{pre}.proj_in", h)
     for i in range(n_blocks):
-        h = _transformer_block(P, f"{pre}.transformer_blocks.{i}", h, ctx, heads, head_dim)
+        h = _transformer_block(P, f"{pre}.transformer_blocks.{i}", h, ctx, heads, head_dim, f_img, f_ctx)
     h = ops.linear(P, f"{pre}.proj_out", h)
     h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
     return h + res
@@ -112,9 +122,10 @@ def global_condition(P, cfg: SDXLCfg, timestep, pooled, original_size, target_si
 
 
 def unet_forward(P, cfg: SDXLCfg, latents, timestep, encoder_hidden_states, encoder_pooler_output,
-                 original_size, target_size, crop_coords_top_left):
+                 original_size, target_size, crop_coords_top_left, rope: dict | None = None):
     """UNet.forward, denoiser.py:1180-1233; block wiring from DownBlocks/MidBlock/UpBlocks
-    constructors (:609-722, :776-826, :860-956)."""
+    constructors (:609-722, :776-826, :860-956).  `rope` = dict(rope_dims, rope_theta, origin_position) runs
+    DenoiserWithRoPE (adapter/rope.py:459-536) instead."""
     ctx = encoder_hidden_states
     _t, g = global_condition(P, cfg, timestep, encoder_pooler_output, original_size, target_size,
                              crop_coords_top_left, latents.dtype)
@@ -138,7 +149,7 @@ def unet_forward(P, cfg: SDXLCfg, latents, timestep, encoder_hidden_states, enco
         else:
             for _ in range(cfg.layers_per_block):
                 x = _res_block(P, f"input_blocks.blocks.{idx}.0", x, g)
-                x = _spatial_transformer(P, f"input_blocks.blocks.{idx}.1", x, ctx, hd, nt)
+                x = _spatial_transformer(P, f"input_blocks.blocks.{idx}.1", x, ctx, hd, nt, rope)
                 skips.append(x)
                 idx += 1
         if i != nstage - 1:
@@ -147,7 +158,7 @@ def unet_forward(P, cfg: SDXLCfg, latents, timestep, encoder_hidden_states, enco
             idx += 1
     # ---- mid ----
     x = _res_block(P, "middle_block.blocks.0", x, g)
-    x = _spatial_transformer(P, "middle_block.blocks.1", x, ctx, hd, cfg.num_transformers_per_block[-1])
+    x = _spatial_transformer(P, "middle_block.blocks.1", x, ctx, hd, cfg.num_transformers_per_block[-1], rope)
     x = _res_block(P, "middle_block.blocks.2", x, g)
     # ---- up ----
     idx = 0
@@ -159,7 +170,7 @@ def unet_forward(P, cfg: SDXLCfg, latents, timestep, encoder_hidden_states, enco
             x = _res_block(P, f"{pre}.0", x, g)
             nxt = 1
             if kind == "TransformerUpBlock2D":
-                x = _spatial_transformer(P, f"{pre}.1", x, ctx, hd, nt)
+                x = _spatial_transformer(P, f"{pre}.1", x, ctx, hd, nt, rope)
                 nxt = 2
             if j == cfg.layers_per_block and i != len(cfg.up_blocks) - 1:
                 x = F.interpolate(x, scale_factor=2, mode="nearest")

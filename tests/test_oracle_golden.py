@@ -5,6 +5,7 @@ import json
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import auraflow as oaura
 from oracle import index_ops, ops
@@ -204,6 +205,73 @@ def test_sdxl_oracle_matches_reference(fixture):
     Pl = add_lora_params({k: v.detach() for k, v in P.items()}, json.loads(meta["lora_keys"]))
     assert sorted(k for k in Pl if ".lora_" in k or k.endswith(".alpha")) == json.loads(meta["lora_keys"])
     losses = _train_lora(Pl, lambda P_: ops.ddpm_loss(T["noise"], fwd(P_, T["noisy"])))
+    torch.testing.assert_close(losses, T["lora.losses"], rtol=2e-3, atol=0)
+
+
+def test_sdxl_rope_flow_match_oracle_matches_reference():
+    """DenoiserWithRoPE (2-D RoPE on attn1/attn2, origin "center", non-square latent) under the
+    flow-matching step of train/sdxl/flow_match.py — tables and position ids exact, rotation exact, forward / loss /
+    gradients / LoRA losses within the CPU-vs-CPU tolerances of the plain SDXL test."""
+    from vision_ft_amd.models.sdxl.adapter.rope import DenoiserConfigWithRoPE, DenoiserWithRoPE, RoPEEmbedder
+    from vision_ft_amd.modules.loss import flow_match as FM
+
+    T, meta = load_golden("sdxl_rope_tiny.safetensors")
+    cfgd, rope = json.loads(meta["config"]), json.loads(meta["rope"])
+    assert rope == dict(rope_dims=[32, 32], rope_theta=10000.0, origin_position="center")  # DenoiserConfigWithRoPE defaults
+    h, w = T["latents"].shape[-2:]
+    # index work and tables: exact, oracle and product (the product builds its tables on the host like the reference)
+    ids = ops.sdxl_image_position_ids(h, w, "center")
+    assert torch.equal(ids, T["ids.image"])
+    assert torch.equal(ops.sdxl_image_position_ids(5, 7, "top_left"), T["ids.image_top_left"])
+    f_img = ops.sdxl_rope_freqs(ids, rope["rope_dims"], rope["rope_theta"])
+    f_ctx = ops.sdxl_rope_freqs(ops.sdxl_context_position_ids(T["ehs"].shape[1]), rope["rope_dims"], rope["rope_theta"])
+    assert torch.equal(torch.view_as_real(f_img), T["freqs.image"])
+    assert torch.equal(torch.view_as_real(f_ctx), T["freqs.context"])
+    emb = RoPEEmbedder(**rope)
+    assert torch.equal(emb.get_image_position_ids(1, h, w)[0], T["ids.image"])
+    assert torch.equal(RoPEEmbedder([32, 32]).get_image_position_ids(1, 5, 7)[0], T["ids.image_top_left"])
+    assert torch.equal(torch.view_as_real(emb.get_image_freqs(1, h, w, torch.device("cpu"))[0]), T["freqs.image"])
+    assert torch.equal(torch.view_as_real(emb.get_context_freqs(1, 11, torch.device("cpu"))[0]), T["freqs.context"])
+    cos, sin = emb.image_table(h, w, torch.device("cpu"))
+    assert torch.equal(cos, T["freqs.image"][..., 0]) and torch.equal(sin, T["freqs.image"][..., 1])
+    assert torch.equal(ops.sdxl_apply_rope(T["apply.in"], f_img), T["apply.out"])
+    # noising and the x0 -> velocity conversion: exact (product functions and oracle restatement)
+    assert torch.equal(ops.flow_scaled_noise(T["latents"], T["t"], T["noise"]), T["noisy"])
+    assert torch.equal(ops.flow_scaled_noise(T["latents"], T["t"], T["noise"], clean_at_zero=True), T["noisy_c0"])
+    torch.manual_seed(123)
+    n2, e2 = FM.prepare_scaled_noised_latents(T["latents"], T["t"], noise_scale=1.0, clean_at_zero=False)
+    assert torch.equal(n2, T["noisy"]) and torch.equal(e2, T["noise"])
+    assert torch.equal(ops.x0_to_velocity(T["latents"], T["noisy"], T["t"]), T["x0_velocity_target"])
+    assert torch.equal(FM.convert_x0_to_velocity(T["latents"], T["noisy"], T["t"]), T["x0_velocity_target"])
+
+    with torch.device("meta"):
+        mod = DenoiserWithRoPE(DenoiserConfigWithRoPE(**cfgd))
+    P = synth_params(mod, 0, meta["checksum"])  # no RoPE parameters: the plain SDXL state dict
+    cfg = osdxl.SDXLCfg(**cfgd)
+    grads = [k[5:] for k in T if k.startswith("grad.")]
+    _leafify(P, grads)
+    x = T["noisy"].clone().requires_grad_(True)
+
+    def fwd(P, x, rope=rope):
+        return osdxl.unet_forward(P, cfg, x, T["t"] * 1000, T["ehs"], T["pooled"], T["original_size"],
+                                  T["target_size"], T["crop"], rope=rope)
+
+    with autocast_cpu():
+        out = fwd(P, x)
+        loss = ops.flow_loss(T["latents"], T["noise"], out)
+        loss_img = F.mse_loss(ops.x0_to_velocity(out, T["noisy"], T["t"]), ops.x0_to_velocity(T["latents"], T["noisy"], T["t"]))
+        out_off = fwd(P, T["noisy"], rope=None)
+    loss.backward()
+    assert rel_err(out, T["out"]) < 2e-3
+    assert rel_err(out_off, T["out_rope_off"]) < 2e-3
+    assert rel_err(out, T["out_rope_off"]) > 2e-2  # the rotation matters at this size: a path that ignores it fails
+    torch.testing.assert_close(loss.float(), T["loss"], rtol=2e-3, atol=0)
+    torch.testing.assert_close(loss_img.float(), T["loss_image_pred"], rtol=2e-3, atol=0)
+    assert rel_err(x.grad, T["d_noisy"]) < 1e-2
+    for g in grads:
+        assert rel_err(P[g].grad, T["grad." + g]) < 2e-2, g
+    Pl = add_lora_params({k: v.detach() for k, v in P.items()}, json.loads(meta["lora_keys"]))
+    losses = _train_lora(Pl, lambda P_: ops.flow_loss(T["latents"], T["noise"], fwd(P_, T["noisy"])))
     torch.testing.assert_close(losses, T["lora.losses"], rtol=2e-3, atol=0)
 
 
