@@ -75,6 +75,66 @@ def test_flow_match_trainer_runs(gpu, tmp_path, prediction):
     assert sorted(tmp_path.glob("tiny_*.safetensors"))
 
 
+def test_real_image_front_half_trains(gpu, tmp_path):
+    """pixels + captions from TextToImageDatasetConfig (cover-resize, random crop, size conditions) through
+    the Trainer.  The frozen VAE / text encoders are outside the hot path: deterministic stand-ins are attached, and the
+    test checks the plumbing — latents of the bucket's shape and the dataset's own size conditions reach the denoiser."""
+    import sys
+
+    import numpy as np
+    from PIL import Image
+
+    sys.path.insert(0, ".")
+    from train.sdxl.text_to_image import SDXLForTextToImageTraining
+    from vision_ft_amd.dataset.text_to_image import TextToImageDatasetConfig
+    from vision_ft_amd.trainer.common import Trainer
+
+    folder = tmp_path / "images"
+    folder.mkdir()
+    rng = np.random.default_rng(0)
+    for i, (w, h) in enumerate([(300, 270), (330, 262), (200, 340), (210, 350), (512, 512)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(folder / f"{i}.png")
+        (folder / f"{i}.txt").write_text(f"a picture number {i}")
+    cfg = _config(tmp_path, True)
+    cfg.dataset = {"folder": str(folder), "batch_size": 2, "bucket_base_size": 256, "step": 64, "min_size": 128, "num_workers": 0}
+    trainer = Trainer(cfg)
+    trainer.register_train_dataset_class(TextToImageDatasetConfig)
+    trainer.register_model_class(SDXLForTextToImageTraining)
+    task = trainer.model
+    with pytest.raises(RuntimeError, match="attach_encoders"):
+        task._stage_image_batch({"image": torch.zeros(1, 3, 8, 8), "caption": ["x"]})
+    seen = []
+
+    def image_encoder(px):  # stand-in for vae.encode(px).sample() * scaling_factor: (B,3,H,W) -> (B,4,H/8,W/8)
+        lat = torch.nn.functional.avg_pool2d(px.float(), 8)
+        return torch.cat([lat, lat[:, :1]], dim=1).to(torch.bfloat16)
+
+    def prompt_encoder(captions):
+        g = torch.Generator().manual_seed(sum(map(len, captions)))
+        return {"ehs": torch.randn(len(captions), 77, 64, generator=g), "pooled": torch.randn(len(captions), 1280, generator=g)}
+
+    task.attach_encoders(image_encoder=image_encoder, prompt_encoder=prompt_encoder)
+    stage = task._stage_image_batch
+
+    def spy(batch):
+        key = stage(batch)
+        lat, cond = task._static[key]
+        seen.append((tuple(lat.shape), cond["original_size"].tolist(), cond["target_size"].tolist(), cond["crop"].tolist(),
+                     tuple(batch["image"].shape)))
+        return key
+
+    task._stage_image_batch = spy
+    trainer.train()
+    assert len(trainer.losses) == 2 * 3 and all(torch.isfinite(torch.tensor(trainer.losses)))  # (2 + 1) bucket batches x 2 epochs
+    for lat_shape, orig, target, crop, px_shape in seen:
+        assert lat_shape == (2, 4, px_shape[2] // 8, px_shape[3] // 8)
+        for o, t, c in zip(orig, target, crop):
+            assert t == [px_shape[2], px_shape[3]]                 # target size = the bucket (h, w)
+            assert o[0] >= t[0] and o[1] >= t[1] and (o[0] == t[0] or o[1] == t[1])  # cover-resized size
+            assert 0 <= c[0] <= o[0] - t[0] and 0 <= c[1] <= o[1] - t[1]
+    assert {s[4][2:] for s in seen} == {(256, 256), (320, 192)}  # (h, w) of the 256x256 and 192x320 buckets
+
+
 @pytest.mark.parametrize("accum", [1, 2])
 def test_graph_replay_takes_the_same_steps_as_eager(gpu, tmp_path, accum):
     """HIP-graph mode is an execution detail: same seeds -> the same per-step losses as the eager loop, with an

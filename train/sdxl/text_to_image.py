@@ -45,6 +45,12 @@ class SDXLForTextToImageTraining(DenoiserTask):
             "crop": torch.zeros(batch, 2, dtype=torch.long, device=dev),
         }
 
+    def conditions_from_batch(self, batch, text_cond):
+        # real-image batches bring their own size conditions (dataset/text_to_image.py; reference train_step :106-112)
+        return {"ehs": text_cond["ehs"].to(torch.bfloat16), "pooled": text_cond["pooled"].to(torch.bfloat16),
+                "original_size": batch["original_size"], "target_size": batch["target_size"],
+                "crop": batch["crop_coords_top_left"]}
+
     def denoise_loss(self, latents, cond):
         # train_step of the reference, :114-143
         timesteps = uniform_randint(latents.shape, latents.device, 0, 1000)

@@ -68,8 +68,46 @@ class DenoiserTask(ModelForTraining):
             lat = make_latents(768, 768, 1, self.latent_channels, self.accelerator.device, seed=0)
             self.denoise_loss(lat, cond)
 
+    # ---- real-image front half (reference train_step: text encode + VAE encode under no_grad, train/sdxl/text_to_image.py:
+    # 114-135).  The frozen encoders themselves are outside the hot path: they are attached as callables.
+    image_encoder = None   # (B,3,H,W) fp16 in -1..1 -> latents (B,C,H/8,W/8), scaling factor applied (`encode_image`)
+    prompt_encoder = None  # list[str] -> dict of text-condition tensors (the keys `make_conditions` produces)
+
+    def attach_encoders(self, image_encoder=None, prompt_encoder=None) -> None:
+        self.image_encoder = image_encoder or self.image_encoder
+        self.prompt_encoder = prompt_encoder or self.prompt_encoder
+
+    def conditions_from_batch(self, batch: dict, text_cond: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        """Task hook: merge the encoded captions with the batch's own conditions (SDXL: the three size conditions)."""
+        return text_cond
+
+    @torch.no_grad()
+    def _stage_image_batch(self, batch: dict) -> tuple:
+        if self.image_encoder is None or self.prompt_encoder is None:
+            raise RuntimeError(
+                "this batch carries pixels and captions (TextToImageDatasetConfig), but no frozen VAE / text encoder is "
+                "attached: call task.attach_encoders(image_encoder=..., prompt_encoder=...) — they are outside the "
+                "MI355X hot path and are not built by vision_ft_amd — or train from SyntheticLatentDatasetConfig")
+        dev = self.accelerator.device
+        images = batch["image"].to(dev, non_blocking=True)
+        lat = self.image_encoder(images)
+        cond = self.conditions_from_batch(batch, self.prompt_encoder(list(batch["caption"])))
+        cond = {k: v.to(dev) for k, v in cond.items()}
+        key = ("image", tuple(lat.shape), tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
+        if key not in self._static:
+            self._static[key] = (lat.clone(), {k: v.clone() for k, v in cond.items()})
+        else:
+            s_lat, s_cond = self._static[key]
+            s_lat.copy_(lat)
+            for k, v in cond.items():
+                s_cond[k].copy_(v)
+        self._key = key
+        return key
+
     def stage_batch(self, batch: dict) -> tuple:
         """Materialise the batch on the device into per-shape static tensors; returns the graph key."""
+        if "image" in batch:
+            return self._stage_image_batch(batch)
         w, h, seeds = batch["width"], batch["height"], batch["seeds"]
         w, h = (int(w[0]) if isinstance(w, (list, tuple)) else int(w)), (int(h[0]) if isinstance(h, (list, tuple)) else int(h))
         key = (w, h, len(seeds))
