@@ -103,6 +103,23 @@ size_t vft_lora_wgrad_workspace(int M, int K, int N, int r);
 int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t, void* d_down,
                     void* d_up, float* workspace, size_t ws_bytes, int M, int K, int N, int r,
                     int64_t ldx, int64_t lddy, float scale, void* stream);
+/* Grouped / in-place form of vft_lora_wgrad2.  `groups` (1..3) adapters share the input x — SDXL's fused q|k|v
+ * projection (sdxl/denoiser.py:57-64): u (M,r) and t (M,r) hold the groups' rank-`rsub` columns side by side (zero
+ * padded to r), dy (M,N) their N/groups output columns side by side.  The gradients go straight into the caller's dense
+ * tensors d_down[g] (rsub,K) and d_up[g] (N/groups,rsub) — with accumulate != 0 they are ADDED to the contents, which
+ * is what torch's AccumulateGrad would do with a returned gradient (the trainer points param.grad into one flat buffer,
+ * src/trainer/common.py:355-365 accumulation semantics). */
+int vft_lora_wgrad2g(const void* x, const void* u, const void* dy, const void* t, void* const* d_down,
+                     void* const* d_up, int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes,
+                     int M, int K, int N, int r, int64_t ldx, int64_t lddy, float scale, void* stream);
+
+/* All derived adapter operands of a model in one launch.  `table` (device memory) holds n descriptors of seven int64:
+ * {src0, src1, src2, dst, kind | groups << 32, r | rp << 32, L}; kind 0: dst (rp,L) = the groups' lora_down (r,L) stacked
+ * and zero-padded to rp rows; kind 1: its transpose (L,rp); kind 2: dst (groups*L, rp) = blockdiag of the groups'
+ * lora_up (L,r), zero-padded; kind 3: its transpose.  These are the forms the rank extension of vft_linear_fwd and
+ * vft_lora_down consume (a fused q|k|v projection uses groups = 3); the reference needs none of them because it runs
+ * the adapter as two extra GEMMs (peft/lora.py:92-104). */
+int vft_lora_pack(const void* table, int n, void* stream);
 
 /* ---- row norms -----------------------------------------------------------------------------
  * LayerNorm / RMSNorm over the last dimension with fp32 statistics, optional per-channel affine
@@ -137,23 +154,29 @@ int vft_qk_norm_rope_bwd(const void* dy, const void* x, const void* weight, cons
 
 /* ---- GroupNorm (+SiLU), NCHW ---------------------------------------------------------------
  * Replaces GroupNorm -> SiLU of the SDXL ResidualBlock (sdxl/denoiser.py:511-551) and the
- * SpatialTransformer norm (:303).  stats/bstats: fp32 [N*G*2] workspaces; dweight/dbias: optional
- * fp32 [C] accumulators.  Accesses are 16 bytes wide when H*W is a multiple of 8 (narrower otherwise).
+ * SpatialTransformer norm (:303).  stats/bstats: fp32 [N*G*2], written by the call (stats is what backward
+ * reads); dweight/dbias: optional fp32 [C], written by the call.  scratch: fp32
+ * [vft_groupnorm_scratch_floats(N, C, HW, G, nhwc, affine)] for the partial sums — every reduction is two-stage with
+ * a fixed order, so results are bit-reproducible (no floating-point atomics; torch's checkpoint recompute,
+ * sdxl/denoiser.py:592-605, sees identical statistics).  Accesses are 16 bytes wide when H*W is a multiple of 8.
  */
+int64_t vft_groupnorm_scratch_floats(int N, int C, int HW, int G, int nhwc, int affine);
 int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats,
-                      int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
+                      float* scratch, int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
 int vft_groupnorm_bwd(const void* x, const void* dy, const float* stats, const void* weight,
-                      const void* bias, void* dx, float* bstats, float* dweight, float* dbias, int N,
-                      int C, int HW, int G, float eps, int fuse_silu, void* stream);
+                      const void* bias, void* dx, float* bstats, float* scratch, float* dweight,
+                      float* dbias, int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
 /* Channels-last variants: x / y / dy / dx are [N][HW][C] (C % 8 == 0, C <= 2560), everything else as
  * above, same statistics layout.  The SDXL UNet runs NHWC end to end on MI355X: the convolutions are
  * NHWC-native and (N, HW, C) is the SpatialTransformer's token layout (sdxl/denoiser.py:303-330), so the
  * reference's permute + reshape copies around every transformer disappear. */
 int vft_groupnorm_nhwc_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats,
-                           int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
+                           float* scratch, int N, int C, int HW, int G, float eps, int fuse_silu,
+                           void* stream);
 int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float* stats, const void* weight,
-                           const void* bias, void* dx, float* bstats, float* dweight, float* dbias,
-                           int N, int C, int HW, int G, float eps, int fuse_silu, void* stream);
+                           const void* bias, void* dx, float* bstats, float* scratch, float* dweight,
+                           float* dbias, int N, int C, int HW, int G, float eps, int fuse_silu,
+                           void* stream);
 
 /* ---- gated activations / gated residual ------------------------------------------------------
  * GEGLU: out[M,F] = proj[:, :F] * gelu(proj[:, F:])   (sdxl/denoiser.py:183-186, exact erf GELU)
@@ -218,6 +241,11 @@ int vft_linear_fwd(const void* x, const void* w, void* y, const void* bias, cons
  * trainers never call it): 0 = automatic choice (default), -1 = first-generation kernel (linear.hip),
  * 1 / 2 / 3 = second-generation kernel (linear8.hip) with a 256x256 / 256x128 / 128x128 output tile. */
 int vft_linear_variant(int variant);
+/* Per-problem tile choice measured on the target (tools/tune_lin8.py -> tuning_tables/gfx950_lin8_tiles.csv): for the
+ * (M, N, K) GEMM (conv = 0) or the implicit-GEMM convolution with M = B*H*W, N = Cout, K = 9*Cin (conv = 1) use tile
+ * cfg 1 / 2 / 3 instead of the analytic choice; cfg 0 removes the entry.  Process-wide; results do not depend on the
+ * tile (same K order per output element), only the speed does. */
+int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg);
 
 /* ---- GEMM (bf16 / NF4 weight) ----------------------------------------------------------------
  * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, weight B row-major [out,in]

@@ -179,3 +179,37 @@ def test_rope_apply_matches_reference_golden(gpu):
     f64 = torch.cat([freqs, torch.stack([torch.ones(freqs.shape[0], 16), torch.zeros(freqs.shape[0], 16)], -1)], dim=1)
     out = applye_rope_frequencies(x.to(gpu), f64)
     assert rel_err(out[..., :32].cpu(), G["rope.out_bf16"]) < 1e-2
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_group_norm_is_bit_reproducible(gpu, nhwc):
+    """No floating-point atomics: statistics, dx and the affine gradients of two launches on the same inputs are
+    bit-identical (what `torch.utils.checkpoint` recompute, src/models/sdxl/denoiser.py:592-605, relies on), at a size
+    where many workgroups contribute to every group (24 x 320 x 64 x 64: 32 groups of 10 channels — a group does not
+    align with the kernels' 8-channel vectors)."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator(device=gpu).manual_seed(0)
+    x = torch.randn(24, 320, 64, 64, generator=g, device=gpu).to(torch.bfloat16)
+    dy = (torch.randn(24, 320, 64, 64, generator=g, device=gpu) * 1e-3).to(torch.bfloat16)
+    if nhwc:
+        x, dy = x.contiguous(memory_format=torch.channels_last), dy.contiguous(memory_format=torch.channels_last)
+    w = torch.randn(320, generator=g, device=gpu).to(torch.bfloat16)
+    b = torch.randn(320, generator=g, device=gpu).to(torch.bfloat16)
+    runs = []
+    for _ in range(3):
+        xi, wi, bi = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = kernels.group_norm(xi, wi, bi, 32, 1e-5, silu=True)
+        y.backward(dy)
+        runs.append((y.detach(), xi.grad, wi.grad, bi.grad))
+    for other in runs[1:]:
+        for a, c in zip(runs[0], other):
+            assert torch.equal(a, c)
+    # and still the right numbers
+    xf = x.float().requires_grad_()
+    wf, bf = w.float().requires_grad_(), b.float().requires_grad_()
+    ref = F.silu(F.group_norm(xf, 32, wf, bf, 1e-5))
+    ref.backward(dy.float())
+    assert rel_err(runs[0][0].float(), ref) < 6e-3
+    assert rel_err(runs[0][1].float(), xf.grad) < 1e-2
+    assert rel_err(runs[0][2].float(), wf.grad) < 1e-2 and rel_err(runs[0][3].float(), bf.grad) < 1e-2

@@ -269,3 +269,68 @@ def test_lora_geglu_down_fused_feedforward(gpu, M, C, r):
     a, b = run(True), run(False)
     for i, (u, v) in enumerate(zip(a, b)):
         assert rel_err(u, v.float()) < 1.2e-2, (i, rel_err(u, v.float()))
+
+
+def test_adapter_pack_forms_and_in_place_gradients(gpu):
+    """One `vft_lora_pack` launch builds the operand forms of every adapter (transposes; the concatenated /
+    block-diagonal / zero-padded forms of a fused q|k|v) exactly; with gradient tensors in place the weight-gradient
+    kernel adds into them (what AccumulateGrad does with a returned gradient) and autograd gets None."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator(device=gpu).manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu).to(torch.bfloat16)  # noqa: E731
+    pack = kernels.AdapterPack(gpu)
+    single = [(rn(4, 640).requires_grad_(), rn(1280, 4).requires_grad_())]
+    wide = [(rn(6, 320).requires_grad_(), rn(640, 6).requires_grad_())]  # rank 6 -> padded to 8
+    qkv = [(rn(4, 640).requires_grad_(), rn(640, 4).requires_grad_()) for _ in range(3)]
+    e1, e2, e3 = pack.add(single, 4), pack.add(wide, 8), pack.add(qkv, 16)
+    pack.finalize()
+    pack.refresh()
+    A, B, At, Bt = kernels._pack_forms(e1, single)
+    assert A is single[0][0] and B is single[0][1]
+    assert torch.equal(At, single[0][0].t()) and torch.equal(Bt, single[0][1].t())
+    A, B, At, Bt = kernels._pack_forms(e2, wide)
+    pad_a = torch.cat([wide[0][0], wide[0][0].new_zeros(2, 320)], 0)
+    pad_b = torch.cat([wide[0][1], wide[0][1].new_zeros(640, 2)], 1)
+    assert torch.equal(A, pad_a) and torch.equal(B, pad_b) and torch.equal(At, pad_a.t()) and torch.equal(Bt, pad_b.t())
+    A, B, At, Bt = kernels._pack_forms(e3, qkv)
+    cat = torch.cat([a for a, _ in qkv] + [qkv[0][0].new_zeros(4, 640)], 0)
+    blk = torch.cat([torch.block_diag(*[b for _, b in qkv]), qkv[0][1].new_zeros(1920, 4)], 1)
+    assert torch.equal(A, cat) and torch.equal(B, blk) and torch.equal(At, cat.t()) and torch.equal(Bt, blk.t())
+    # a parameter update invalidates the entry until the next refresh
+    with torch.no_grad():
+        single[0][0].add_(1.0)
+    assert kernels._pack_forms(e1, single) is None
+    pack.refresh()
+    assert torch.equal(kernels._pack_forms(e1, single)[2], single[0][0].t())
+
+    # in-place weight gradients == returned gradients added to what the buffers held
+    x = rn(2, 512, 640)
+    W = rn(1280, 640)
+    dy = rn(2, 512, 1280)
+    Aq, Bq = single[0]
+    base = torch.nn.Linear(640, 1280, bias=False, device=gpu, dtype=torch.bfloat16).requires_grad_(False)
+    with torch.no_grad():
+        base.weight.copy_(W)
+    before = dict(kernels.PACK_STATS)
+    y = kernels.lora_linear(x, base, Aq, Bq, 0.25, pack=e1)
+    dA_ret, dB_ret = torch.autograd.grad(y, (Aq, Bq), dy, retain_graph=True)  # no .grad tensors yet: returned
+    Aq.grad, Bq.grad = rn(4, 640) * 0.1, rn(1280, 4) * 0.1
+    held_a, held_b = Aq.grad.clone(), Bq.grad.clone()
+    y.backward(dy)
+    after = kernels.PACK_STATS
+    assert after["pack_hit"] == before["pack_hit"] + 1 and after["grad_in_place"] == before["grad_in_place"] + 1
+    assert rel_err(Aq.grad.float(), held_a.float() + dA_ret.float()) < 4e-3
+    assert rel_err(Bq.grad.float(), held_b.float() + dB_ret.float()) < 4e-3
+    # fused q|k|v: three adapters' gradients from one grouped launch, in place, against the returned form
+    wqkv = rn(1920, 640)
+    xq = rn(2, 256, 640)
+    outs = kernels.lora_qkv(xq, wqkv, qkv, 0.25, 10, pack=e3)
+    douts = [rn(*o.shape) for o in outs]
+    flat = [p_ for pair in qkv for p_ in pair]
+    ret = torch.autograd.grad(outs, flat, douts, retain_graph=True)
+    for p_ in flat:
+        p_.grad = torch.zeros_like(p_)
+    torch.autograd.backward(outs, douts)
+    for p_, r_ in zip(flat, ret):
+        assert rel_err(p_.grad.float(), r_.float()) < 4e-3

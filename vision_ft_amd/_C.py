@@ -47,14 +47,17 @@ SIGNATURES: dict[str, tuple] = {
     "vft_lora_bwd_dx": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vft_lora_wgrad2": (c_int, [c_void_p] * 7 + [c_size_t] + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
+    "vft_lora_wgrad2g": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p, c_size_t] + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
+    "vft_lora_pack": (c_int, [c_void_p, c_int, c_void_p]),
     "vft_norm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "vft_norm_bwd_dx": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "vft_qk_norm_rope_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [_I64P, c_int64, c_int, c_float, c_void_p]),
     "vft_qk_norm_rope_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [_I64P, c_int64, c_int, c_void_p]),
-    "vft_groupnorm_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_int, c_void_p]),
-    "vft_groupnorm_bwd": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_float, c_int, c_void_p]),
-    "vft_groupnorm_nhwc_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_int, c_void_p]),
-    "vft_groupnorm_nhwc_bwd": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "vft_groupnorm_scratch_floats": (c_int64, [c_int] * 6),
+    "vft_groupnorm_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "vft_groupnorm_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "vft_groupnorm_nhwc_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "vft_groupnorm_nhwc_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "vft_geglu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "vft_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "vft_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -64,6 +67,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_conv3x3_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "vft_linear_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_int64] * 4 + [c_void_p]),
     "vft_linear_variant": (c_int, [c_int]),
+    "vft_linear_tile_hint": (c_int, [c_int] * 5),
     "vft_attn_variant": (c_int, [c_int]),
     "vft_gemm_nt_bf16": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_int64] * 3 + [c_void_p]),
     "vft_gemm_nf4": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_float, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
@@ -87,7 +91,31 @@ def lib() -> ctypes.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = cdll
+        if os.environ.get("VFT_NO_TILE_TABLE", "") != "1":
+            load_tile_table()
     return _lib
+
+
+TILE_TABLE = os.path.join(_HERE, "tuning_tables", "gfx950_lin8_tiles.csv")
+
+
+def load_tile_table(path: str | None = None) -> int:
+    """Register the measured tile choice of every (M, N, K, conv) row of the committed table with the library
+    (vft_linear_tile_hint; tools/tune_lin8.py writes the table).  Shapes that are not listed keep the analytic choice.
+    Returns the number of rows registered."""
+    path = path or TILE_TABLE
+    if not os.path.exists(path):
+        return 0
+    n = 0
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#") or line.startswith("M,"):
+                continue
+            m, nn, k, conv, cfg = (int(v) for v in line.split(",")[:5])
+            check(lib().vft_linear_tile_hint(m, nn, k, conv, cfg), "vft_linear_tile_hint")
+            n += 1
+    return n
 
 
 def check(status: int, what: str) -> None:

@@ -6,9 +6,11 @@
 //
 // Two HBM passes per direction (statistics, then apply): a group of an NCHW tensor is one contiguous
 // run of (C/G)·H·W elements, so both passes stream with 16-byte accesses.  The statistics pass runs
-// one workgroup per (n, c) plane and folds its two partial sums into the group's accumulator with
-// two fp32 atomics (B·C·2 atomics in total — negligible).  Algorithmic bytes: forward 3·N·2 (two
-// reads + one write of the tensor), backward 5·N·2.
+// one workgroup per (n, c) plane (NCHW) or per row chunk (NHWC) and writes its partial sums to a scratch
+// buffer; a tiny finalize kernel adds them in a FIXED order, so statistics, dx and the affine gradients are
+// bit-reproducible from run to run (no floating-point atomics anywhere) and a checkpoint recompute sees the
+// statistics the forward saw.  Algorithmic bytes: forward 3·N·2 (two reads + one write of the tensor),
+// backward 5·N·2.
 #include "vft_common.h"
 
 namespace {
@@ -39,9 +41,9 @@ __device__ __forceinline__ void stv(bf16_t* p, const float (&v)[V]) {
     }
 }
 
-// stats[(n*G+g)*2 + {0,1}] += (Σx, Σx²) of plane (n, c)
+// part[(n*C+c)*2 + {0,1}] = (Σx, Σx²) of plane (n, c); gn_finalize_kernel folds the planes of a group in channel order
 template <int V>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int C,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int C,
                                                        int HW, int cpg) {
     __shared__ float red[4];
     const int plane = blockIdx.x;  // n*C + c
@@ -60,11 +62,37 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     s1 = block_sum<4>(s1, red);
     s2 = block_sum<4>(s2, red);
     if (threadIdx.x == 0) {
-        const int G = C / cpg;
-        float* st = stats + ((int64_t)n * G + c / cpg) * 2;
-        atomicAdd(st, s1);
-        atomicAdd(st + 1, s2);
+        part[(int64_t)plane * 2] = s1;
+        part[(int64_t)plane * 2 + 1] = s2;
     }
+    (void)n, (void)c, (void)cpg;
+}
+
+// out[row*2 + k] = Σ_{j < nparts} part[(row*nparts + j)*2 + k]   (row = (n, g); parts = the group's planes (NCHW) or
+// the image's row chunks laid out [n][g][chunk] (NHWC)), added in index order: deterministic
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int64_t rows2, int nparts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows2) return;
+    const int64_t row = i >> 1;
+    const int k = (int)(i & 1);
+    float v = 0.f;
+    for (int j = 0; j < nparts; ++j) v += part[(row * nparts + j) * 2 + k];
+    out[i] = v;
+}
+
+// affine gradients: dw[c] = Σ_blk cpart[blk][0][c], db[c] = Σ_blk cpart[blk][1][c], blocks in index order
+__global__ __launch_bounds__(256) void gn_finalize_affine_kernel(const float* __restrict__ cpart, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int nblk, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < nblk; ++j) {
+        a += cpart[((int64_t)j * 2) * C + c];
+        b += cpart[((int64_t)j * 2 + 1) * C + c];
+    }
+    if (dw) dw[c] = a;
+    if (db) db[c] = b;
 }
 
 template <int V>
@@ -95,13 +123,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
-// bstats[(n*G+g)*2 + {0,1}] += (Σ g, Σ g·xhat), g = dz·w_c, dz = dy·silu'(z) (or dy);
-// optionally dw[c] += Σ dz·xhat, db[c] += Σ dz
+// part[(n*C+c)*2 + {0,1}] = (Σ g, Σ g·xhat) of plane (n, c), g = dz·w_c, dz = dy·silu'(z) (or dy);
+// optionally cpart[n][0][c] = Σ dz·xhat, cpart[n][1][c] = Σ dz (the affine gradients' per-image partials)
 template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ stats, const bf16_t* __restrict__ w,
-                                                           const bf16_t* __restrict__ b, float* __restrict__ bstats,
-                                                           float* __restrict__ dw, float* __restrict__ db, int C, int HW,
+                                                           const bf16_t* __restrict__ b, float* __restrict__ part,
+                                                           float* __restrict__ cpart, int C, int HW,
                                                            int cpg, float eps, int silu) {
     __shared__ float red[4];
     const int plane = blockIdx.x;
@@ -131,11 +159,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
     sz = block_sum<4>(sz, red);
     szx = block_sum<4>(szx, red);
     if (threadIdx.x == 0) {
-        float* bs = bstats + ((int64_t)n * G + c / cpg) * 2;
-        atomicAdd(bs, sz * wc);
-        atomicAdd(bs + 1, szx * wc);
-        if (dw) atomicAdd(dw + c, szx);
-        if (db) atomicAdd(db + c, sz);
+        part[(int64_t)plane * 2] = sz * wc;
+        part[(int64_t)plane * 2 + 1] = szx * wc;
+        if (cpart) {
+            cpart[((int64_t)n * 2) * C + c] = szx;
+            cpart[((int64_t)n * 2 + 1) * C + c] = sz;
+        }
     }
 }
 
@@ -196,35 +225,53 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<bf16x8*>(p) = t;
 }
 
-// fold 8 per-channel pairs into the LDS per-group accumulators (runs of equal group first)
-__device__ __forceinline__ void fold_groups(float* gacc, int c0, int cpg, const float (&a)[8], const float (&b)[8]) {
-    int g = c0 / cpg;
-    int left = cpg - (c0 - g * cpg);  // channels of group g remaining from c0 on
-    float ra = 0.f, rb = 0.f;
+// Block-level fold of the threads' 8-channel partial pairs, in a fixed order (no atomics): the R row slots of a channel
+// are added in slot order, then a group's channels in channel order.  L: (2R + 2)·C floats of LDS.
+//   part[((n*G + g) * nchunks + chunk) * 2 + {0,1}] = the block's sums of group g (scale: per-channel factor or null)
+//   cpart[(blk*2 + {0,1}) * C + c]                  = the block's per-channel sums (b first, then a), when wanted
+__device__ __forceinline__ void fold_block(float* L, const NhwcGeom& gm, int lr, int cv, const float (&a)[8],
+                                           const float (&b)[8], const float* wscale, float* part, int64_t part_row0,
+                                           int nchunks, int chunk, float* cpart, int64_t blk) {
+    const int C = gm.C, R = gm.R;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (left == 0) {
-            atomicAdd(&gacc[g * 2], ra);
-            atomicAdd(&gacc[g * 2 + 1], rb);
-            ra = rb = 0.f;
-            ++g;
-            left = cpg;
-        }
-        ra += a[i];
-        rb += b[i];
-        --left;
+        L[(lr)*C + cv * 8 + i] = a[i];
+        L[(R + lr) * C + cv * 8 + i] = b[i];
     }
-    atomicAdd(&gacc[g * 2], ra);
-    atomicAdd(&gacc[g * 2 + 1], rb);
+    __syncthreads();
+    float* pc = L + 2 * R * C;  // [2][C]
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < R; ++q) {
+            sa += L[q * C + c];
+            sb += L[(R + q) * C + c];
+        }
+        if (cpart) {
+            cpart[(blk * 2) * C + c] = sb;
+            cpart[(blk * 2 + 1) * C + c] = sa;
+        }
+        const float wc = wscale ? wscale[c] : 1.f;
+        pc[c] = sa * wc;
+        pc[C + c] = sb * wc;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < gm.G; g += blockDim.x) {
+        float sa = 0.f, sb = 0.f;
+        for (int j = 0; j < gm.cpg; ++j) {
+            sa += pc[g * gm.cpg + j];
+            sb += pc[C + g * gm.cpg + j];
+        }
+        float* o = part + ((part_row0 + g) * nchunks + chunk) * 2;
+        o[0] = sa;
+        o[1] = sb;
+    }
 }
 
-__global__ __launch_bounds__(320) void gn_nhwc_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(320) void gn_nhwc_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
                                                             NhwcGeom gm) {
-    extern __shared__ float gacc[];  // [G*2]
+    extern __shared__ float gacc[];  // (2R + 2)·C
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
-    for (int i = tid; i < gm.G * 2; i += blockDim.x) gacc[i] = 0.f;
-    __syncthreads();
     const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
     const int r0 = blockIdx.x * gm.rows_per_block;
     const int r1 = min(r0 + gm.rows_per_block, gm.HW);
@@ -254,9 +301,7 @@ __global__ __launch_bounds__(320) void gn_nhwc_stats_kernel(const bf16_t* __rest
             s2[i] += v[i] * v[i];
         }
     }
-    fold_groups(gacc, cv * 8, gm.cpg, s1, s2);
-    __syncthreads();
-    for (int i = tid; i < gm.G * 2; i += blockDim.x) atomicAdd(stats + (int64_t)n * gm.G * 2 + i, gacc[i]);
+    fold_block(gacc, gm, lr, cv, s1, s2, nullptr, part, (int64_t)n * gm.G, gridDim.x, blockIdx.x, nullptr, 0);
 }
 
 // per-channel constants of thread's 8 channels
@@ -324,14 +369,11 @@ __global__ __launch_bounds__(320) void gn_nhwc_apply_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(320) void gn_nhwc_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                 const float* __restrict__ stats,
                                                                 const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
-                                                                float* __restrict__ bstats, float* __restrict__ dw,
-                                                                float* __restrict__ db, NhwcGeom gm, float eps, int silu) {
-    extern __shared__ float gacc[];  // [G*2] (+ [2][C] when the affine gradients are wanted)
+                                                                float* __restrict__ part, float* __restrict__ cpart,
+                                                                NhwcGeom gm, float eps, int silu) {
+    extern __shared__ float gacc[];  // (2R + 3)·C: fold_block's image + the channels' weights
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
-    const int nacc = gm.G * 2 + ((dw != nullptr || db != nullptr) ? 2 * gm.C : 0);
-    for (int i = tid; i < nacc; i += blockDim.x) gacc[i] = 0.f;
-    __syncthreads();
     const int lr = tid / gm.CV, cv = tid - lr * gm.CV;
     ChanConst k;
     load_chan_const(k, stats, w, b, n, cv * 8, gm, eps);
@@ -363,30 +405,11 @@ __global__ __launch_bounds__(320) void gn_nhwc_bwd_stats_kernel(const bf16_t* __
             }
         }
     }
-    const bool wgrad = dw != nullptr || db != nullptr;  // block-uniform
-    if (wgrad) {  // fold the block's row slots through LDS first: one global atomic per channel per block
-        float* cacc = gacc + gm.G * 2;  // [2][C], zeroed below before use
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            atomicAdd(&cacc[cv * 8 + i], szx[i]);
-            atomicAdd(&cacc[gm.C + cv * 8 + i], sz[i]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        sz[i] *= k.w[i];
-        szx[i] *= k.w[i];
-    }
-    fold_groups(gacc, cv * 8, gm.cpg, sz, szx);
-    __syncthreads();
-    for (int i = tid; i < gm.G * 2; i += blockDim.x) atomicAdd(bstats + (int64_t)n * gm.G * 2 + i, gacc[i]);
-    if (wgrad) {
-        const float* cacc = gacc + gm.G * 2;
-        for (int c = tid; c < gm.C; c += blockDim.x) {
-            if (dw) atomicAdd(dw + c, cacc[c]);
-            if (db) atomicAdd(db + c, cacc[gm.C + c]);
-        }
-    }
+    // group sums take g = dz·w_c: the weights as an LDS vector for fold_block's per-channel pass
+    float* wl = gacc + (2 * gm.R + 2) * gm.C;
+    for (int c = tid; c < gm.C; c += blockDim.x) wl[c] = w ? (float)w[c] : 1.f;
+    fold_block(gacc, gm, lr, cv, sz, szx, wl, part, (int64_t)n * gm.G, gridDim.x, blockIdx.x, cpart,
+               (int64_t)n * gridDim.x + blockIdx.x);
 }
 
 __global__ __launch_bounds__(320) void gn_nhwc_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -474,17 +497,36 @@ int gn_args(const char* name, int N, int C, int HW, int G) {
 
 }  // namespace
 
-// stats: [N*G*2] fp32 workspace, written here (saved for backward)
-extern "C" int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats, int N, int C,
-                                 int HW, int G, float eps, int fuse_silu, void* stream) {
-    VFT_CHECK_ARG(x && y && stats, "vft_groupnorm_fwd: null pointer");
+// Scratch floats the four entry points need for their partial sums (see the header comment): forward and backward use
+// the same amount; `affine` adds the per-block channel partials of dweight / dbias.
+static int64_t nhwc_chunks(int N, int C, int HW, int G) {
+    NhwcGeom gm;
+    if (nhwc_geom("vft_groupnorm_scratch_floats", gm, N, C, HW, G, nullptr, nullptr, nullptr)) return -1;
+    return (HW + gm.rows_per_block - 1) / gm.rows_per_block;
+}
+extern "C" int64_t vft_groupnorm_scratch_floats(int N, int C, int HW, int G, int nhwc, int affine) {
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G != 0) return -1;
+    if (!nhwc) return (int64_t)N * C * 2 + (affine ? (int64_t)N * 2 * C : 0);
+    const int64_t ch = nhwc_chunks(N, C, HW, G);
+    if (ch < 0) return -1;
+    return (int64_t)N * G * ch * 2 + (affine ? (int64_t)N * ch * 2 * C : 0);
+}
+
+static void finalize_groups(const float* part, float* out, int64_t rows, int nparts, hipStream_t st) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, st, part, out, rows * 2, nparts);
+}
+
+// stats: [N*G*2] fp32, written here (saved for backward); scratch: vft_groupnorm_scratch_floats(..., 0, 0) floats
+extern "C" int vft_groupnorm_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats, float* scratch,
+                                 int N, int C, int HW, int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && y && stats && scratch, "vft_groupnorm_fwd: null pointer");
     if (gn_args("vft_groupnorm_fwd", N, C, HW, G)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(float), st);
     const int V = vec_width(HW, x, y);
 #define VFT_GN_FWD(VV)                                                                                                  \
     {                                                                                                                   \
-        hipLaunchKernelGGL(gn_stats_kernel<VV>, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, stats, C, HW, C / G);  \
+        hipLaunchKernelGGL(gn_stats_kernel<VV>, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, scratch, C, HW, C / G); \
+        finalize_groups(scratch, stats, (int64_t)N * G, C / G, st);                                                     \
         const int64_t nvec = (int64_t)N * C * HW / VV;                                                                  \
         hipLaunchKernelGGL(gn_apply_kernel<VV>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, stats,        \
                            (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)y, C, HW, C / G, eps, fuse_silu, nvec); \
@@ -500,23 +542,24 @@ extern "C" int vft_groupnorm_fwd(const void* x, void* y, const void* weight, con
     return 0;
 }
 
-// bstats: [N*G*2] fp32 scratch; dweight/dbias: optional [C] fp32 accumulators (zeroed here)
+// bstats: [N*G*2] fp32 (written here); dweight/dbias: optional [C] fp32 (written here); scratch:
+// vft_groupnorm_scratch_floats(..., 0, dweight || dbias) floats
 extern "C" int vft_groupnorm_bwd(const void* x, const void* dy, const float* stats, const void* weight, const void* bias,
-                                 void* dx, float* bstats, float* dweight, float* dbias, int N, int C, int HW, int G,
-                                 float eps, int fuse_silu, void* stream) {
-    VFT_CHECK_ARG(x && dy && stats && dx && bstats, "vft_groupnorm_bwd: null pointer");
+                                 void* dx, float* bstats, float* scratch, float* dweight, float* dbias, int N, int C, int HW,
+                                 int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && dy && stats && dx && bstats && scratch, "vft_groupnorm_bwd: null pointer");
     if (gn_args("vft_groupnorm_bwd", N, C, HW, G)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(bstats, 0, (size_t)N * G * 2 * sizeof(float), st);
-    if (dweight) hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
-    if (dbias) hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
+    const bool affine = dweight || dbias;
+    float* cpart = affine ? scratch + (int64_t)N * C * 2 : nullptr;
     int V = vec_width(HW, x, dy);
     if (((uintptr_t)dx & (2 * V - 1)) != 0) V = 1;
 #define VFT_GN_BWD(VV)                                                                                                    \
     {                                                                                                                     \
         hipLaunchKernelGGL(gn_bwd_stats_kernel<VV>, dim3(N * C), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,   \
-                           stats, (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, C, HW, C / G, eps,  \
+                           stats, (const bf16_t*)weight, (const bf16_t*)bias, scratch, cpart, C, HW, C / G, eps,          \
                            fuse_silu);                                                                                    \
+        finalize_groups(scratch, bstats, (int64_t)N * G, C / G, st);                                                      \
         const int64_t nvec = (int64_t)N * C * HW / VV;                                                                    \
         hipLaunchKernelGGL(gn_bwd_dx_kernel<VV>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x,                \
                            (const bf16_t*)dy, stats, bstats, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, C,  \
@@ -529,21 +572,25 @@ extern "C" int vft_groupnorm_bwd(const void* x, const void* dy, const float* sta
         default: VFT_GN_BWD(1); break;
     }
 #undef VFT_GN_BWD
+    if (affine)
+        hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cpart, dweight, dbias, N, C);
     VFT_CHECK_LAUNCH("vft_groupnorm_bwd");
     return 0;
 }
 
 // ---- channels-last (NHWC) entry points: same arguments, x / y / dy / dx are [N][HW][C] ----
-extern "C" int vft_groupnorm_nhwc_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats, int N,
-                                      int C, int HW, int G, float eps, int fuse_silu, void* stream) {
-    VFT_CHECK_ARG(x && y && stats, "vft_groupnorm_nhwc_fwd: null pointer");
+extern "C" int vft_groupnorm_nhwc_fwd(const void* x, void* y, const void* weight, const void* bias, float* stats,
+                                      float* scratch, int N, int C, int HW, int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && y && stats && scratch, "vft_groupnorm_nhwc_fwd: null pointer");
     if (gn_args("vft_groupnorm_nhwc_fwd", N, C, HW, G)) return 1;
     NhwcGeom gm;
     if (nhwc_geom("vft_groupnorm_nhwc_fwd", gm, N, C, HW, G, x, y, nullptr)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(stats, 0, (size_t)N * G * 2 * sizeof(float), st);
     const dim3 grid((HW + gm.rows_per_block - 1) / gm.rows_per_block, N), block(gm.CV * gm.R);
-    hipLaunchKernelGGL(gn_nhwc_stats_kernel, grid, block, G * 2 * sizeof(float), st, (const bf16_t*)x, stats, gm);
+    const size_t lds = (size_t)(2 * gm.R + 2) * C * sizeof(float);
+    VFT_CHECK_ARG(lds <= 64 * 1024, "vft_groupnorm_nhwc_fwd: C=%d needs %zu bytes of LDS", C, lds);
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel, grid, block, lds, st, (const bf16_t*)x, scratch, gm);
+    finalize_groups(scratch, stats, (int64_t)N * G, (int)grid.x, st);
     hipLaunchKernelGGL(gn_nhwc_apply_kernel, grid, block, 0, st, (const bf16_t*)x, stats, (const bf16_t*)weight,
                        (const bf16_t*)bias, (bf16_t*)y, gm, eps, fuse_silu);
     VFT_CHECK_LAUNCH("vft_groupnorm_nhwc_fwd");
@@ -551,21 +598,25 @@ extern "C" int vft_groupnorm_nhwc_fwd(const void* x, void* y, const void* weight
 }
 
 extern "C" int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float* stats, const void* weight,
-                                      const void* bias, void* dx, float* bstats, float* dweight, float* dbias, int N, int C,
-                                      int HW, int G, float eps, int fuse_silu, void* stream) {
-    VFT_CHECK_ARG(x && dy && stats && dx && bstats, "vft_groupnorm_nhwc_bwd: null pointer");
+                                      const void* bias, void* dx, float* bstats, float* scratch, float* dweight,
+                                      float* dbias, int N, int C, int HW, int G, float eps, int fuse_silu, void* stream) {
+    VFT_CHECK_ARG(x && dy && stats && dx && bstats && scratch, "vft_groupnorm_nhwc_bwd: null pointer");
     if (gn_args("vft_groupnorm_nhwc_bwd", N, C, HW, G)) return 1;
     NhwcGeom gm;
     if (nhwc_geom("vft_groupnorm_nhwc_bwd", gm, N, C, HW, G, x, dy, dx)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(bstats, 0, (size_t)N * G * 2 * sizeof(float), st);
-    if (dweight) hipMemsetAsync(dweight, 0, (size_t)C * sizeof(float), st);
-    if (dbias) hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
     const dim3 grid((HW + gm.rows_per_block - 1) / gm.rows_per_block, N), block(gm.CV * gm.R);
-    const size_t lds = (G * 2 + ((dweight || dbias) ? 2 * C : 0)) * sizeof(float);
+    const bool affine = dweight || dbias;
+    float* cpart = affine ? scratch + (int64_t)N * G * grid.x * 2 : nullptr;
+    const size_t lds = (size_t)(2 * gm.R + 3) * C * sizeof(float);
+    VFT_CHECK_ARG(lds <= 64 * 1024, "vft_groupnorm_nhwc_bwd: C=%d needs %zu bytes of LDS", C, lds);
     hipLaunchKernelGGL(gn_nhwc_bwd_stats_kernel, grid, block, lds, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, stats, (const bf16_t*)weight, (const bf16_t*)bias, bstats, dweight, dbias, gm, eps,
+                       (const bf16_t*)dy, stats, (const bf16_t*)weight, (const bf16_t*)bias, scratch, cpart, gm, eps,
                        fuse_silu);
+    finalize_groups(scratch, bstats, (int64_t)N * G, (int)grid.x, st);
+    if (affine)
+        hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cpart, dweight, dbias,
+                           (int)(N * grid.x), C);
     hipLaunchKernelGGL(gn_nhwc_bwd_dx_kernel, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats,
                        (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, gm, eps, fuse_silu);
     VFT_CHECK_LAUNCH("vft_groupnorm_nhwc_bwd");

@@ -498,6 +498,40 @@ void launch_linear(const LinParams& p, hipStream_t st) {
 
 }  // namespace
 
+// Measured tile choices per problem (vft_linear_tile_hint): consulted before the analytic model of vft_lin8_pick.
+// Key = (M, N, K, conv); a handful to a few hundred entries, set once at start-up from the committed table
+// (vision_ft_amd/tuning_tables/gfx950_lin8_tiles.csv); read on every launch (host side only).
+#include <mutex>
+#include <unordered_map>
+namespace {
+std::unordered_map<uint64_t, int> g_tile_hints;
+std::mutex g_tile_mu;
+inline uint64_t tile_key(int M, int N, int K, int conv) {
+    // M < 2^31, N, K < 2^20 for every operand this library accepts (2 GiB descriptors); mixed into 64 bits
+    uint64_t h = (uint64_t)(uint32_t)M * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t)(uint32_t)N << 21) ^ ((uint64_t)(uint32_t)K << 42) ^ (uint64_t)(conv & 1);
+    return h * 0xD6E8FEB86659FD93ull + (uint64_t)(uint32_t)N * 31u + (uint64_t)(uint32_t)K;
+}
+int pick_tile(int M, int N, int K, int conv) {
+    {
+        std::lock_guard<std::mutex> g(g_tile_mu);
+        auto it = g_tile_hints.find(tile_key(M, N, K, conv));
+        if (it != g_tile_hints.end()) return it->second;
+    }
+    return vft_lin8_pick(M, N, K);
+}
+}  // namespace
+
+extern "C" int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg) {
+    VFT_CHECK_ARG(M > 0 && N > 0 && K > 0 && cfg >= 0 && cfg <= 3, "vft_linear_tile_hint: need M,N,K>0 and cfg in 0..3 (0 clears)");
+    std::lock_guard<std::mutex> g(g_tile_mu);
+    if (cfg == 0)
+        g_tile_hints.erase(tile_key(M, N, K, conv));
+    else
+        g_tile_hints[tile_key(M, N, K, conv)] = cfg;
+    return 0;
+}
+
 extern "C" int vft_linear_variant(int variant) {
     VFT_CHECK_ARG(variant >= -1 && variant <= 3, "vft_linear_variant: %d is not in -1..3", variant);
     g_variant = variant;
@@ -525,7 +559,7 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
     q.x = p.x, q.w = p.w, q.y = p.y, q.bias = p.bias, q.res = p.res, q.ex = p.ex, q.ew = p.ew;
     q.M = M, q.N = N, q.K = K, q.r = p.r, q.ldx = ldx, q.ldw = ldw, q.ldy = ldy, q.ldres = ldres;
     if (g_variant >= 0 && q.r <= 16 && vft_lin8_fits(q, false)) {
-        vft_lin8_launch(q, g_variant > 0 ? g_variant : vft_lin8_pick(M, N, K), false, (hipStream_t)stream);
+        vft_lin8_launch(q, g_variant > 0 ? g_variant : pick_tile(M, N, K, 0), false, (hipStream_t)stream);
         VFT_CHECK_LAUNCH("vft_linear_fwd");
         return 0;
     }
@@ -570,7 +604,7 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
     q.M = p.M, q.N = p.N, q.K = p.K, q.r = 0, q.ldx = p.ldx, q.ldw = p.ldw, q.ldy = p.ldy, q.ldres = 0;
     q.cH = H, q.cW = W, q.cC = Cin;
     if (Cin % 64 == 0 && g_variant >= 0 && vft_lin8_fits(q, true)) {
-        vft_lin8_launch(q, g_variant > 0 ? g_variant : vft_lin8_pick(p.M, p.N, p.K), true, (hipStream_t)stream);
+        vft_lin8_launch(q, g_variant > 0 ? g_variant : pick_tile(p.M, p.N, p.K, 1), true, (hipStream_t)stream);
         VFT_CHECK_LAUNCH("vft_conv3x3_fwd");
         return 0;
     }

@@ -226,9 +226,12 @@ struct WgradProblem {
     const bf16_t* x;
     const bf16_t* t;
     float* part;
-    bf16_t* out;
-    int K;
-    int64_t ldx, oj, ok;
+    bf16_t* out[3];  // one gradient tensor per adapter group (1, or 3 for a fused q|k|v), each dense
+    int K;           // columns of x: the long dimension of this problem's gradient
+    int64_t ldx;
+    int kind;        // 0: d(lora_down) (rsub, K) per group, group = j / rsub;  1: d(lora_up) (K / groups, rsub) per group,
+                     // group = k / ksub and only the diagonal block j in [g rsub, (g+1) rsub) exists
+    int groups, rsub, ksub;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0, int col0, int lane) {
@@ -316,16 +319,72 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0
     }
 }
 
-// stage 2: out(j, k) = s · Σ_mb P[mb][k][j]   (bf16, strided output), both problems in one launch
-__global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(WgradProblem p0, WgradProblem p1, int nmb, int r, float s) {
+// stage 2: out_g(j, k) (+)= s · Σ_mb P[mb][k][j]   (bf16; straight into the gradient tensors, padded rank rows /
+// off-diagonal blocks of a grouped problem dropped), both problems in one launch
+__global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(WgradProblem p0, WgradProblem p1, int nmb, int r, float s,
+                                                                int accumulate) {
     const WgradProblem& p = blockIdx.y == 0 ? p0 : p1;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t ne = (int64_t)p.K * r;
     if (e >= ne) return;
+    const int k = (int)(e / r), j = (int)(e % r);
+    bf16_t* dst;
+    if (p.kind == 0) {
+        const int g = j / p.rsub;
+        if (g >= p.groups) return;  // zero-padded rank rows
+        dst = p.out[g] + (int64_t)(j - g * p.rsub) * p.K + k;
+    } else {
+        const int g = k / p.ksub, jj = j - g * p.rsub;
+        if (jj < 0 || jj >= p.rsub) return;  // off the block diagonal / padded rank columns
+        dst = p.out[g] + (int64_t)(k - g * p.ksub) * p.rsub + jj;
+    }
     float v = 0.f;
     for (int mb = 0; mb < nmb; ++mb) v += p.part[(int64_t)mb * ne + e];
-    const int k = (int)(e / r), j = (int)(e % r);
-    p.out[(int64_t)j * p.oj + (int64_t)k * p.ok] = (bf16_t)(v * s);
+    v *= s;
+    if (accumulate) v += (float)*dst;
+    *dst = (bf16_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adapter operand forms for the fused projection GEMM, all layers of a model in ONE launch (vft_lora_pack).
+// The GEMM's rank extension wants lora_up as (N, rp) and — for the data gradient — lora_down transposed (K, rp);
+// vft_lora_down wants lora_up transposed (rp, N); a fused q|k|v projection wants the three adapters concatenated
+// (lora_down rows) / block-diagonal (lora_up), zero-padded to the extension rank rp.  Each is a tiny tensor, but built
+// per layer and per step with tensor ops they are ~3 000 launches; here one descriptor per output tensor:
+//   kind 0  dst (rp, L)      = [A_0; A_1; A_2; 0]                    A_g = src[g] (r, L)
+//   kind 1  dst (L, rp)      = the transpose of kind 0
+//   kind 2  dst (G L, rp)    = blockdiag(B_0, B_1, B_2) | 0           B_g = src[g] (L, r)
+//   kind 3  dst (rp, G L)    = the transpose of kind 2
+// ---------------------------------------------------------------------------------------------
+struct PackDesc {
+    const bf16_t* src[3];
+    bf16_t* dst;
+    int32_t kind, groups, r, rp;
+    int64_t L;
+};
+static_assert(sizeof(PackDesc) == 56, "PackDesc is built by the host as 7 x int64");
+
+__global__ __launch_bounds__(256) void lora_pack_kernel(const PackDesc* __restrict__ table) {
+    const PackDesc d = table[blockIdx.y];
+    const int64_t rows = (d.kind == 0 || d.kind == 3) ? d.rp : (d.kind == 1 ? d.L : d.groups * d.L);
+    const int64_t cols = (d.kind == 0) ? d.L : (d.kind == 3 ? d.groups * d.L : d.rp);
+    const int64_t n = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / cols, c = e - i * cols;
+        // (j, l): rank index in the padded rank, position along L (kinds 0/1) or along G*L (kinds 2/3)
+        const int64_t j = (d.kind == 0 || d.kind == 3) ? i : c;
+        const int64_t l = (d.kind == 0 || d.kind == 3) ? c : i;
+        bf16_t v = (bf16_t)0.f;
+        if (d.kind <= 1) {
+            const int g = (int)(j / d.r);
+            if (g < d.groups) v = d.src[g][(j - (int64_t)g * d.r) * d.L + l];
+        } else {
+            const int g = (int)(l / d.L);
+            const int64_t jj = j - (int64_t)g * d.r;
+            if (jj >= 0 && jj < d.r) v = d.src[g][(l - (int64_t)g * d.L) * d.r + jj];
+        }
+        d.dst[e] = v;
+    }
 }
 
 int chk(bool c, const char* msg) {
@@ -399,19 +458,26 @@ extern "C" size_t vft_lora_wgrad_workspace(int M, int K, int N, int r) {
     return (size_t)((M + rpb - 1) / rpb) * (size_t)(K + N) * (size_t)r * sizeof(float);
 }
 
-extern "C" int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t, void* d_down, void* d_up,
-                               float* workspace, size_t ws_bytes, int M, int K, int N, int r, int64_t ldx, int64_t lddy,
-                               float scale, void* stream) {
+static int wgrad_launch(const void* x, const void* u, const void* dy, const void* t, void* const* d_down, void* const* d_up,
+                        int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes, int M, int K, int N, int r,
+                        int64_t ldx, int64_t lddy, float scale, void* stream, const char* name) {
     if (chk(x && u && dy && t && d_down && d_up && workspace, "vft_lora_wgrad2: null pointer")) return 1;
-    VFT_CHECK_ARG(M > 0 && K > 0 && N > 0 && r > 0 && r <= 32, "vft_lora_wgrad2: need M,K,N>0 and 0<r<=32");
-    VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "vft_lora_wgrad2: K, N, strides must be multiples of 8");
-    VFT_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "vft_lora_wgrad2: activations must be 16-byte aligned");
-    VFT_CHECK_ARG(ws_bytes >= vft_lora_wgrad_workspace(M, K, N, r), "vft_lora_wgrad2: workspace too small");
+    VFT_CHECK_ARG(M > 0 && K > 0 && N > 0 && r > 0 && r <= 32, "%s: need M,K,N>0 and 0<r<=32", name);
+    VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "%s: K, N, strides must be multiples of 8", name);
+    VFT_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "%s: activations must be 16-byte aligned", name);
+    VFT_CHECK_ARG(groups >= 1 && groups <= 3 && rsub >= 1 && groups * rsub <= r && N % groups == 0,
+                  "%s: need 1 <= groups <= 3, groups * rsub <= r and N %% groups == 0 (groups=%d rsub=%d r=%d N=%d)", name, groups, rsub, r, N);
+    VFT_CHECK_ARG(ws_bytes >= vft_lora_wgrad_workspace(M, K, N, r), "%s: workspace too small", name);
     const int rpb = wgrad_rows_per_block(M, K, N);
     const int nmb = (M + rpb - 1) / rpb;
-    WgradProblem pa{(const bf16_t*)x, (const bf16_t*)u, workspace, (bf16_t*)d_down, K, ldx, (int64_t)K, 1};  // dA (r,K)
-    WgradProblem pb{(const bf16_t*)dy, (const bf16_t*)t, workspace + (size_t)nmb * K * r, (bf16_t*)d_up, N, lddy, 1,
-                    (int64_t)r};  // dB (N,r)
+    WgradProblem pa{(const bf16_t*)x, (const bf16_t*)u, workspace, {nullptr, nullptr, nullptr}, K, ldx, 0, groups, rsub, 0};
+    WgradProblem pb{(const bf16_t*)dy, (const bf16_t*)t, workspace + (size_t)nmb * K * r, {nullptr, nullptr, nullptr}, N, lddy,
+                    1, groups, rsub, N / groups};
+    for (int g = 0; g < groups; ++g) {
+        if (chk(d_down[g] && d_up[g], "vft_lora_wgrad2: null gradient pointer")) return 1;
+        pa.out[g] = (bf16_t*)d_down[g];
+        pb.out[g] = (bf16_t*)d_up[g];
+    }
     const size_t lds = 64 * WG_LD * 2 + 64 * (size_t)r * 2;
     const int kmax = K > N ? K : N;
     hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, 2), dim3(256), lds,
@@ -419,7 +485,36 @@ extern "C" int vft_lora_wgrad2(const void* x, const void* u, const void* dy, con
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(partial)");
     const int64_t ne = (int64_t)kmax * r;
     hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 2), dim3(256), 0,
-                       (hipStream_t)stream, pa, pb, nmb, r, scale);
+                       (hipStream_t)stream, pa, pb, nmb, r, scale, accumulate);
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(reduce)");
+    return 0;
+}
+
+extern "C" int vft_lora_wgrad2(const void* x, const void* u, const void* dy, const void* t, void* d_down, void* d_up,
+                               float* workspace, size_t ws_bytes, int M, int K, int N, int r, int64_t ldx, int64_t lddy,
+                               float scale, void* stream) {
+    void* dd[1] = {d_down};
+    void* du[1] = {d_up};
+    return wgrad_launch(x, u, dy, t, dd, du, 1, r, 0, workspace, ws_bytes, M, K, N, r, ldx, lddy, scale, stream, "vft_lora_wgrad2");
+}
+
+// Grouped form: `groups` adapters that share x (a fused q|k|v projection: u / t carry the groups' rank columns side by
+// side, dy their output columns side by side), rank `rsub` each inside the padded rank r.  Gradients are written straight
+// into the caller's tensors — d_down[g] (rsub, K), d_up[g] (N / groups, rsub), dense — and with accumulate != 0 added to
+// what they hold (the trainer's flat gradient buffer: no autograd accumulation pass, no slicing of padded results).
+extern "C" int vft_lora_wgrad2g(const void* x, const void* u, const void* dy, const void* t, void* const* d_down,
+                                void* const* d_up, int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes,
+                                int M, int K, int N, int r, int64_t ldx, int64_t lddy, float scale, void* stream) {
+    return wgrad_launch(x, u, dy, t, d_down, d_up, groups, rsub, accumulate, workspace, ws_bytes, M, K, N, r, ldx, lddy, scale,
+                        stream, "vft_lora_wgrad2g");
+}
+
+// table: n descriptors of 7 x int64 in device memory: {src0, src1, src2, dst, kind | groups << 32, r | rp << 32, L}
+// (see PackDesc above).  One launch rebuilds every derived adapter operand of a model; graph-capturable.
+extern "C" int vft_lora_pack(const void* table, int n, void* stream) {
+    if (chk(table != nullptr, "vft_lora_pack: null table")) return 1;
+    VFT_CHECK_ARG(n > 0 && n <= 65535, "vft_lora_pack: need 0 < n <= 65535 descriptors (got %d)", n);
+    hipLaunchKernelGGL(lora_pack_kernel, dim3(16, (unsigned)n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table);
+    VFT_CHECK_LAUNCH("vft_lora_pack");
     return 0;
 }

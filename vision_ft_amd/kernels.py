@@ -349,9 +349,14 @@ class _GroupNorm(torch.autograd.Function):
         w, b_ = _bf16_or_none(weight), _bf16_or_none(bias)
         y = torch.empty_like(x)  # preserves the memory format
         stats = torch.empty(N * groups * 2, dtype=torch.float32, device=x.device)
+        nscr = _C.lib().vft_groupnorm_scratch_floats(N, C, H * W, groups, int(nhwc), 0)
+        if nscr < 0:
+            _C.check(1, "vft_groupnorm_scratch_floats")
+        scratch = torch.empty(nscr, dtype=torch.float32, device=x.device)  # partial sums, folded in a fixed order
         fn = _C.lib().vft_groupnorm_nhwc_fwd if nhwc else _C.lib().vft_groupnorm_fwd
         with torch.cuda.device(x.device), _Timed("groupnorm_fwd", 6.0 * x.numel()):
-            st = fn(_ptr(x), _ptr(y), _ptr(w), _ptr(b_), _ptr(stats), N, C, H * W, groups, float(eps), int(silu), _stream())
+            st = fn(_ptr(x), _ptr(y), _ptr(w), _ptr(b_), _ptr(stats), _ptr(scratch), N, C, H * W, groups, float(eps), int(silu),
+                    _stream())
         _C.check(st, "vft_groupnorm_fwd")
         ctx.save_for_backward(x, w, b_, stats)
         ctx.meta = (groups, eps, silu, weight, bias, nhwc)
@@ -369,10 +374,12 @@ class _GroupNorm(torch.autograd.Function):
         need_b = ctx.needs_input_grad[2] and bias is not None
         dwf = torch.empty(C, dtype=torch.float32, device=x.device) if need_w else None
         dbf = torch.empty(C, dtype=torch.float32, device=x.device) if need_b else None
+        nscr = _C.lib().vft_groupnorm_scratch_floats(N, C, H * W, groups, int(nhwc), int(need_w or need_b))
+        scratch = torch.empty(max(nscr, 1), dtype=torch.float32, device=x.device)
         fn = _C.lib().vft_groupnorm_nhwc_bwd if nhwc else _C.lib().vft_groupnorm_bwd
         with torch.cuda.device(x.device), _Timed("groupnorm_bwd", 10.0 * x.numel()):
-            st = fn(_ptr(x), _ptr(dy), _ptr(stats), _ptr(w), _ptr(b_), _ptr(dx), _ptr(bstats), _ptr(dwf), _ptr(dbf),
-                    N, C, H * W, groups, float(eps), int(silu), _stream())
+            st = fn(_ptr(x), _ptr(dy), _ptr(stats), _ptr(w), _ptr(b_), _ptr(dx), _ptr(bstats), _ptr(scratch), _ptr(dwf),
+                    _ptr(dbf), N, C, H * W, groups, float(eps), int(silu), _stream())
         _C.check(st, "vft_groupnorm_bwd")
         dw = dwf.to(weight.dtype) if need_w else None
         db = dbf.to(bias.dtype) if need_b else None
@@ -569,6 +576,138 @@ def _lora_wgrad2(x2, u, dy2, t, A, B, s: float):
     return dA, dB
 
 
+# How often the adapter layers found their operand forms in the model's AdapterPack / wrote weight gradients in place
+# (host-side counters: tests and the bench check that the fast paths are the ones that run)
+PACK_STATS = {"pack_hit": 0, "pack_miss": 0, "grad_in_place": 0, "grad_returned": 0}
+
+
+def _grad_target(p: torch.Tensor | None):
+    """The tensor a weight gradient may be accumulated into directly: the parameter's existing dense bf16 `.grad` (the
+    trainer points it into the flat gradient buffer).  None -> the gradient has to be returned to autograd."""
+    g = getattr(p, "grad", None) if p is not None else None
+    if g is None or g.dtype != torch.bfloat16 or not g.is_contiguous() or not g.is_cuda or g.shape != p.shape:
+        return None
+    return g
+
+
+def _lora_wgrad_into(x2, u, dy2, t, params, r: int, rp: int, s: float):
+    """Weight gradients of `len(params)` adapters that share x2 — params = [(lora_down, lora_up)], 1 or 3 (fused q|k|v);
+    u / t (M, rp) carry their rank-r columns side by side, dy2 their output columns side by side.
+
+    When every parameter already has a gradient tensor the kernel ADDS into it (what AccumulateGrad would do with a
+    returned tensor — minus one elementwise launch per parameter) and the function returns None for each; otherwise the
+    gradients are returned: [dA_0, dB_0, dA_1, ...]."""
+    G = len(params)
+    M, K = x2.shape
+    N = dy2.shape[1]
+    targets = [(_grad_target(a), _grad_target(b)) for a, b in params]
+    inplace = all(ga is not None and gb is not None for ga, gb in targets)
+    PACK_STATS["grad_in_place" if inplace else "grad_returned"] += G
+    if not inplace:
+        targets = [(torch.empty((r, K), dtype=torch.bfloat16, device=x2.device),
+                    torch.empty((N // G, r), dtype=torch.bfloat16, device=x2.device)) for _ in range(G)]
+    nbytes = _C.lib().vft_lora_wgrad_workspace(M, K, N, rp)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
+    dd = (ctypes.c_void_p * 3)(*[t_[0].data_ptr() for t_ in targets])
+    du = (ctypes.c_void_p * 3)(*[t_[1].data_ptr() for t_ in targets])
+    with _Timed("lora_wgrad2", 2.0 * M * (K + N)):
+        st = _C.lib().vft_lora_wgrad2g(_ptr(x2), _ptr(u), _ptr(dy2), _ptr(t), dd, du, G, r, 1 if inplace else 0, _ptr(ws), nbytes,
+                                       M, K, N, rp, x2.stride(0), dy2.stride(0), float(s), _stream())
+    _C.check(st, "vft_lora_wgrad2g")
+    if inplace:
+        return [None] * (2 * G)
+    return [g for pair in targets for g in pair]
+
+
+class AdapterPack:
+    """Operand forms of every LoRA adapter of a model that the fused projection GEMM consumes — lora_up transposed
+    (for u = dy B), lora_down transposed (the data gradient's rank extension), the concatenated / block-diagonal /
+    zero-padded forms of a fused q|k|v — kept in one flat buffer and rebuilt by ONE kernel launch (`vft_lora_pack`) at
+    the start of each forward of the model, instead of ~4 tiny tensor ops per layer and step.
+
+    Entries are created by `modules.peft.functional.build_adapter_pack`; a layer uses its entry only while the entry's
+    snapshot of the parameters' version counters is current (i.e. the pack was refreshed after the last optimizer
+    step), otherwise it falls back to building the forms itself."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.entries: list[dict] = []
+        self._descs: list[tuple] = []  # (srcs, name, kind, groups, r, rp, L) per derived tensor
+        self._table = None
+        self._flat = None
+        self._ptrs: tuple = ()
+
+    def add(self, params: list[tuple[torch.Tensor, torch.Tensor]], rp: int) -> dict:
+        """params = [(lora_down (r,K), lora_up (N,r))] * groups (all the same shape).  Returns the entry, whose tensors
+        `A` (rp,K), `B` (groups*N, rp), `At` (K,rp), `Bt` (rp, groups*N) exist after `finalize()`."""
+        (A0, B0), G = params[0], len(params)
+        r, K = A0.shape
+        N = B0.shape[0]
+        e = {"params": params, "r": r, "rp": rp, "G": G, "K": K, "N": N, "ver": None,
+             "alias": G == 1 and rp == r}  # then A / B are the parameters themselves
+        self.entries.append(e)
+        return e
+
+    def finalize(self) -> None:
+        total, plan = 0, []
+        for e in self.entries:
+            G, rp, K, N = e["G"], e["rp"], e["K"], e["N"]
+            shapes = {"At": ((K, rp), 1), "Bt": ((rp, G * N), 3)}
+            if not e["alias"]:
+                shapes.update({"A": ((rp, K), 0), "B": ((G * N, rp), 2)})
+            for name, (shape, kind) in shapes.items():
+                n = shape[0] * shape[1]
+                plan.append((e, name, shape, kind, total))
+                total += (n + 7) // 8 * 8  # 16-byte aligned starts
+        self._flat = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+        self._plan = plan
+        for e, name, shape, kind, off in plan:
+            e[name] = self._flat[off: off + shape[0] * shape[1]].view(shape)
+        self._build_table()
+
+    def _src_ptrs(self) -> tuple:
+        return tuple(p.data_ptr() for e in self.entries for pair in e["params"] for p in pair)
+
+    def _build_table(self) -> None:
+        rows = []
+        for e, name, shape, kind, off in self._plan:
+            which = 0 if kind <= 1 else 1  # lora_down for kinds 0/1, lora_up for kinds 2/3
+            src = [pair[which].data_ptr() for pair in e["params"]] + [0, 0]
+            L = e["K"] if kind <= 1 else e["N"]
+            rows.append([src[0], src[1], src[2], e[name].data_ptr(), kind | (e["G"] << 32), e["r"] | (e["rp"] << 32), L])
+        self._table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._ptrs = self._src_ptrs()
+
+    def refresh(self) -> None:
+        """Rebuild every derived tensor from the current parameter values (one launch; graph-capturable)."""
+        if self._flat is None:
+            return
+        if self._src_ptrs() != self._ptrs:  # parameters were re-allocated (.to(), load_weights): new source addresses
+            if torch.cuda.is_current_stream_capturing():
+                for e in self.entries:
+                    e["ver"] = None
+                return
+            self._build_table()
+        with torch.cuda.device(self.device):
+            st = _C.lib().vft_lora_pack(_ptr(self._table), self._table.shape[0], _stream())
+        _C.check(st, "vft_lora_pack")
+        for e in self.entries:
+            e["ver"] = tuple(p._version for pair in e["params"] for p in pair)
+
+
+def _pack_forms(entry: dict | None, params) -> tuple | None:
+    """(A, B, At, Bt) of a pack entry if it is current for `params`, else None."""
+    ok = (entry is not None and entry["ver"] is not None and len(params) == entry["G"]
+          and all(a is ea and b is eb for (a, b), (ea, eb) in zip(params, entry["params"]))
+          and entry["ver"] == tuple(p._version for pair in params for p in pair))
+    PACK_STATS["pack_hit" if ok else "pack_miss"] += 1
+    if not ok:
+        return None
+    if entry["alias"]:
+        return params[0][0], params[0][1], entry["At"], entry["Bt"]
+    return entry["A"], entry["B"], entry["At"], entry["Bt"]
+
+
 class _LoRALinear(torch.autograd.Function):
     """y = x Wᵀ + b + s·(x Aᵀ) Bᵀ with a frozen base (W, b).  The base products are a GEMM (library for
     bf16 weights, the NF4-fused kernel for 4-bit weights); everything rank-sized is the HIP kernels
@@ -679,39 +818,45 @@ def _bf16_rows(t: torch.Tensor | None) -> torch.Tensor | None:
 class _LoRALinearFused(torch.autograd.Function):
     """residual + x W^T + b + s (x A^T) B^T, one GEMM launch per direction (reference: LoRALinear.forward,
     src/modules/peft/lora.py:92-104 = three GEMMs, a scale and an add; the residual is the transformer block's
-    `x + layer(x)`, src/models/sdxl/denoiser.py:273-284)."""
+    `x + layer(x)`, src/models/sdxl/denoiser.py:273-284).  `pack`: the layer's AdapterPack entry (operand forms built
+    once per step for the whole model); without it they are built here."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, A, B, s, residual=None):
+    def forward(ctx, x, weight, bias, A, B, s, residual=None, pack=None):
         x2 = _rows(x)
         r = A.shape[0]
         rp = _ext_rank(r)
-        A_p, B_p = _pad_rank_rows(A.contiguous(), rp), _pad_rank_cols(B.contiguous(), rp)
+        forms = _pack_forms(pack, [(A, B)])
+        if forms is None:
+            A_p, B_p = _pad_rank_rows(A.contiguous(), rp), _pad_rank_cols(B.contiguous(), rp)
+            At = Bt = None
+        else:
+            A_p, B_p, At, Bt = forms
         res2 = _bf16_rows(residual)
         with torch.cuda.device(x.device):
             t = lora_down(x2, A_p, s)  # (M, rp), pre-scaled
             y2 = linear_fused(x2, weight, _bf16_or_none(bias), residual=res2, ext_x=t, ext_w=B_p)
-        ctx.save_for_backward(x2, t, weight, A_p, B_p)
+        ctx.save_for_backward(x2, t, weight, A_p, B_p, At, Bt)
+        ctx.params = (A, B)
         ctx.s, ctx.r, ctx.xshape = s, r, x.shape
         ctx.res_shape = residual.shape if residual is not None else None
         return y2.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, t, weight, A_p, B_p = ctx.saved_tensors
+        x2, t, weight, A_p, B_p, At, Bt = ctx.saved_tensors
         s, r = ctx.s, ctx.r
         dy2 = _bf16_rows(dy)
         dx = dA = dB = None
         with torch.cuda.device(dy.device):
-            u = lora_down(dy2, B_p.t().contiguous(), s)  # (M, rp) = s dy B
+            u = lora_down(dy2, Bt if Bt is not None else B_p.t().contiguous(), s)  # (M, rp) = s dy B
             if ctx.needs_input_grad[0]:
-                dx2 = linear_fused(dy2, _transposed_weight(weight), None, ext_x=u, ext_w=A_p.t().contiguous())
+                dx2 = linear_fused(dy2, _transposed_weight(weight), None, ext_x=u, ext_w=At if At is not None else A_p.t().contiguous())
                 dx = dx2.view(ctx.xshape)
             if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-                dA, dB = _lora_wgrad2(x2, u, dy2, t, A_p, B_p, 1.0)
-                dA, dB = dA[:r], dB[:, :r]
+                dA, dB = _lora_wgrad_into(x2, u, dy2, t, [ctx.params], r, A_p.shape[0], 1.0)
         dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[6] else None
-        return dx, None, None, dA, dB, None, dres
+        return dx, None, None, dA, dB, None, dres, None
 
 
 class _LoRAQKVFused(torch.autograd.Function):
@@ -719,27 +864,34 @@ class _LoRAQKVFused(torch.autograd.Function):
     src/models/sdxl/denoiser.py:32-94) as ONE GEMM per direction over the concatenated frozen weights, the three
     adapters as one rank-3r extension: A_cat = [Aq; Ak; Av] (3r, C), B_blk = blockdiag(Bq, Bk, Bv) (3N, 3r).
     Forward returns (B,H,S,D) views of the (tokens, 3N) output; backward takes the attention kernel's single
-    dq|dk|dv buffer."""
+    dq|dk|dv buffer.  `pack`: the attention module's AdapterPack entry (A_cat, B_blk and their transposes)."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, s, heads):
+    def forward(ctx, x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, s, heads, pack=None):
         Bsz, S, C = x.shape
         x2 = _rows(x)
         r, N = Aq.shape[0], Bq.shape[0]
         rp = _ext_rank(3 * r)
-        A_cat = _pad_rank_rows(torch.cat([Aq, Ak, Av], 0), rp)
-        B_blk = _pad_rank_cols(torch.block_diag(Bq, Bk, Bv), rp)
+        params = [(Aq, Bq), (Ak, Bk), (Av, Bv)]
+        forms = _pack_forms(pack, params)
+        if forms is None:
+            A_cat = _pad_rank_rows(torch.cat([Aq, Ak, Av], 0), rp)
+            B_blk = _pad_rank_cols(torch.block_diag(Bq, Bk, Bv), rp)
+            At = Bt = None
+        else:
+            A_cat, B_blk, At, Bt = forms
         with torch.cuda.device(x.device):
             t = lora_down(x2, A_cat, s)
             y = linear_fused(x2, wqkv, None, ext_x=t, ext_w=B_blk)  # (M, 3N)
-        ctx.save_for_backward(x2, wqkv, t, A_cat, B_blk)
+        ctx.save_for_backward(x2, wqkv, t, A_cat, B_blk, At, Bt)
+        ctx.params = params
         ctx.s, ctx.r, ctx.N, ctx.xshape = s, r, N, x.shape
         y5 = y.view(Bsz, S, 3, heads, N // heads)
         return tuple(y5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
-        x2, wqkv, t, A_cat, B_blk = ctx.saved_tensors
+        x2, wqkv, t, A_cat, B_blk, At, Bt = ctx.saved_tensors
         s, r, N = ctx.s, ctx.r, ctx.N
         M = x2.shape[0]
         esz = dq.element_size()
@@ -752,16 +904,14 @@ class _LoRAQKVFused(torch.autograd.Function):
             dy = torch.cat([g.permute(0, 2, 1, 3).reshape(M, N) for g in (dq, dk, dv)], dim=1).to(torch.bfloat16)
         grads = [None] * 6
         with torch.cuda.device(dy.device):
-            u = lora_down(dy, B_blk.t().contiguous(), s)  # (M, rp) = s dy blockdiag(B)
+            u = lora_down(dy, Bt if Bt is not None else B_blk.t().contiguous(), s)  # (M, rp) = s dy blockdiag(B)
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = linear_fused(dy, _transposed_weight(wqkv), None, ext_x=u, ext_w=A_cat.t().contiguous()).view(ctx.xshape)
+                dx = linear_fused(dy, _transposed_weight(wqkv), None, ext_x=u,
+                                  ext_w=At if At is not None else A_cat.t().contiguous()).view(ctx.xshape)
             if any(ctx.needs_input_grad[2:8]):
-                dA_cat, dB_blk = _lora_wgrad2(x2, u, dy, t, A_cat, B_blk, 1.0)
-                for i in range(3):
-                    grads[2 * i] = dA_cat[i * r:(i + 1) * r]
-                    grads[2 * i + 1] = dB_blk[i * N:(i + 1) * N, i * r:(i + 1) * r]
-        return (dx, None, *grads, None, None)
+                grads = _lora_wgrad_into(x2, u, dy, t, ctx.params, r, A_cat.shape[0], 1.0)
+        return (dx, None, *grads, None, None, None)
 
 
 class _LoRAQKV(torch.autograd.Function):
@@ -833,14 +983,14 @@ class _LoRAQKV(torch.autograd.Function):
         return (dx, None, *grads, None, None)
 
 
-def lora_qkv(x: torch.Tensor, wqkv: torch.Tensor, adapters, scale: float, heads: int):
+def lora_qkv(x: torch.Tensor, wqkv: torch.Tensor, adapters, scale: float, heads: int, pack: dict | None = None):
     """(q, k, v) as (B,H,S,D) views for three LoRA-wrapped bias-free projections of `x` (B,S,C);
     wqkv = cat of the frozen base weights (3N, C); adapters = [(lora_down, lora_up)] * 3."""
     _ready(x, wqkv)
     _require_gpu(x, wqkv)
     (Aq, Bq), (Ak, Bk), (Av, Bv) = adapters
     if FUSED_LORA_GEMM and fused_lora_eligible(wqkv, 3 * Aq.shape[0]) and Bq.shape[0] % 64 == 0:
-        return _LoRAQKVFused.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads))
+        return _LoRAQKVFused.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads), pack)
     return _LoRAQKV.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads))
 
 
@@ -851,37 +1001,38 @@ class _QLoRALinear(torch.autograd.Function):
     (reference: LoRALinear over BnbLinear4bit = bnb dequant kernel + GEMM + 3 adapter GEMMs + scale + add)."""
 
     @staticmethod
-    def forward(ctx, x, bias, A, B, s, qstate, residual=None):
+    def forward(ctx, x, bias, A, B, s, qstate, residual=None, pack=None):
         x2 = _rows(x)
-        A, B = A.contiguous(), B.contiguous()
-        res2 = None
-        if residual is not None:
-            res2 = residual.reshape(-1, residual.shape[-1])
-            if res2.stride(-1) != 1 or res2.stride(0) % 8 != 0 or res2.dtype != torch.bfloat16:
-                res2 = res2.to(torch.bfloat16).contiguous()
+        forms = _pack_forms(pack, [(A, B)])
+        if forms is None:
+            A_c, B_c, At, Bt = A.contiguous(), B.contiguous(), None, None
+        else:
+            A_c, B_c, At, Bt = forms
+        res2 = _bf16_rows(residual)
         with torch.cuda.device(x.device):
-            t = lora_down(x2, A)
-            y2 = _nf4_gemm(x2, qstate, bias, False, ext_x=t, ext_w=(B * s).to(torch.bfloat16), residual=res2)
-        ctx.save_for_backward(x2, t, A, B)
+            t = lora_down(x2, A_c, s)  # pre-scaled, so lora_up / lora_down enter the GEMMs as stored
+            y2 = _nf4_gemm(x2, qstate, bias, False, ext_x=t, ext_w=B_c, residual=res2)
+        ctx.save_for_backward(x2, t, A_c, B_c, At, Bt)
+        ctx.params = (A, B)
         ctx.s, ctx.qstate, ctx.xshape = s, qstate, x.shape
         ctx.res_shape = residual.shape if residual is not None else None
         return y2.view(*x.shape[:-1], B.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, t, A, B = ctx.saved_tensors
+        x2, t, A, B, At, Bt = ctx.saved_tensors
         s = ctx.s
-        dy2 = _rows(dy)
+        dy2 = _bf16_rows(dy)
         dx = dA = dB = None
         with torch.cuda.device(dy.device):
-            u = lora_down(dy2, B.t().contiguous())  # (M, r) = dy . B
+            u = lora_down(dy2, Bt if Bt is not None else B.t().contiguous(), s)  # (M, r) = s dy . B
             if ctx.needs_input_grad[0]:
-                dx2 = _nf4_gemm(dy2, ctx.qstate, None, True, ext_x=u, ext_w=(A.t() * s).to(torch.bfloat16).contiguous())
+                dx2 = _nf4_gemm(dy2, ctx.qstate, None, True, ext_x=u, ext_w=At if At is not None else A.t().contiguous())
                 dx = dx2.view(ctx.xshape)
             if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-                dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B, s)
+                dA, dB = _lora_wgrad_into(x2, u, dy2, t, [ctx.params], A.shape[0], A.shape[0], 1.0)
         dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[6] else None
-        return dx, None, dA, dB, None, None, dres
+        return dx, None, dA, dB, None, None, dres, None
 
 
 class _LoRALinearDeferred(torch.autograd.Function):
@@ -1011,15 +1162,15 @@ class _GeGLUDown(torch.autograd.Function):
 
 
 def lora_geglu_down(x: torch.Tensor, up_base, up_A, up_B, s1: float, down_base, down_A, down_B, s2: float,
-                    residual: torch.Tensor | None = None) -> torch.Tensor:
+                    residual: torch.Tensor | None = None, up_pack: dict | None = None, down_pack: dict | None = None) -> torch.Tensor:
     """residual + down(geglu(up(x))) for two LoRA-wrapped bf16 Linears (the SDXL FeedForward), fused as described in
     `_GeGLUDown` / `_LoRALinearDeferred`."""
     _ready(x, up_A, up_B, down_A, down_B)
     _require_gpu(x, up_A, up_B, down_A, down_B)
     if (FUSED_LORA_GEMM and fused_lora_eligible(up_base.weight, up_A.shape[0]) and fused_lora_eligible(down_base.weight, down_A.shape[0])):
         # both adapters ride in their projection's GEMM (forward and data gradient): plain GEGLU in between
-        proj = _LoRALinearFused.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1), None)
-        return _LoRALinearFused.apply(geglu(proj), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual)
+        proj = _LoRALinearFused.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1), None, up_pack)
+        return _LoRALinearFused.apply(geglu(proj), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual, down_pack)
     proj, t1 = _LoRALinearDeferred.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1))
     return _GeGLUDown.apply(proj, t1, up_B.detach(), float(s1), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual)
 
@@ -1070,7 +1221,7 @@ class _LoRABranch(torch.autograd.Function):
 
 
 def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.Tensor, scale: float,
-                residual: torch.Tensor | None = None) -> torch.Tensor:
+                residual: torch.Tensor | None = None, pack: dict | None = None) -> torch.Tensor:
     """base(x) + scale * (x @ lora_down^T) @ lora_up^T (+ residual) with the rank-sized work in fused HIP kernels.
 
     `base` is the wrapped layer: a plain ``nn.Linear`` takes the fully fused path (dx is produced in
@@ -1081,13 +1232,13 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
         raise ValueError(f"LoRA rank {lora_down.shape[0]} > 16 is not supported by the MI355X kernels")
     if type(base) is torch.nn.Linear and base.weight.dtype == torch.bfloat16:
         if FUSED_LORA_GEMM and fused_lora_eligible(base.weight, lora_down.shape[0]):
-            return _LoRALinearFused.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), residual)
+            return _LoRALinearFused.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), residual, pack)
         return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None, residual)
     if hasattr(base, "quant_state"):  # NF4Linear: dequant-fused GEMM for the base products
         q = base.quant_state()
         r = lora_down.shape[0]
         if r in (4, 8, 16) and q.in_features % 64 == 0 and q.out_features % 64 == 0:
-            return _QLoRALinear.apply(x, base.bias, lora_down, lora_up, float(scale), q, residual)
+            return _QLoRALinear.apply(x, base.bias, lora_down, lora_up, float(scale), q, residual, pack)
         return _LoRALinear.apply(x, None, base.bias, lora_down, lora_up, float(scale), q, residual)
     y = base(x)
     if not y.is_contiguous():
@@ -1113,6 +1264,11 @@ def gemm_nt(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = 
     return out
 
 
+# Problem sizes seen by the fused GEMM / implicit-GEMM convolution (tools/tune_lin8.py switches this on for one step of
+# each workload to know what to time): None = off, else a set of ("lin", M, N, K) / ("conv", B, H, W, Cin, Cout).
+SHAPE_LOG: set | None = None
+
+
 def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
                  residual: torch.Tensor | None = None, ext_x: torch.Tensor | None = None,
                  ext_w: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -1124,6 +1280,8 @@ def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
     r = ext_x.shape[1] if ext_x is not None else 0
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.add(("lin", M, N, K))
     with torch.cuda.device(x2.device), _Timed("linear_fwd", 2.0 * M * N * (K + r)):
         st = _C.lib().vft_linear_fwd(_ptr(x2), _ptr(weight), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ext_x), _ptr(ext_w),
                                      M, N, K, r, x2.stride(0), weight.stride(0), out.stride(0),
@@ -1145,6 +1303,8 @@ def conv3x3_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dil
 
 def _conv3x3_call(x_nhwc: torch.Tensor, w_ohwi: torch.Tensor, bias, B, H, W, Cin, Cout, tag: str) -> torch.Tensor:
     y = torch.empty((B, Cout, H, W), dtype=torch.bfloat16, device=x_nhwc.device, memory_format=torch.channels_last)
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.add(("conv", B, H, W, Cin, Cout))
     with torch.cuda.device(x_nhwc.device), _Timed(tag, 18.0 * B * H * W * Cin * Cout):
         st = _C.lib().vft_conv3x3_fwd(_ptr(x_nhwc), _ptr(w_ohwi), _ptr(y), _ptr(bias), B, H, W, Cin, Cout, _stream())
     _C.check(st, "vft_conv3x3_fwd")

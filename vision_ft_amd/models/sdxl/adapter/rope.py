@@ -137,7 +137,7 @@ class SelfAttentionWithRoPE(SelfAttention, _WithRoPE):
         if wqkv is not None:
             q, k, v = kernels.lora_qkv(hidden_states, wqkv,
                                        [(p.lora_down.weight, p.lora_up.weight) for p in (self.to_q, self.to_k, self.to_v)],
-                                       self.to_q._scale(), self.num_heads)
+                                       self.to_q._scale(), self.num_heads, pack=self.__dict__.get("_vft_qkv_pack"))
         else:
             q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
             k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)

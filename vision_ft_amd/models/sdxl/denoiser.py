@@ -88,7 +88,7 @@ class SelfAttention(nn.Module):
         if wqkv is not None:
             q, k, v = kernels.lora_qkv(hidden_states, wqkv,
                                        [(p.lora_down.weight, p.lora_up.weight) for p in (self.to_q, self.to_k, self.to_v)],
-                                       self.to_q._scale(), self.num_heads)
+                                       self.to_q._scale(), self.num_heads, pack=self.__dict__.get("_vft_qkv_pack"))
         else:
             q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
             k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)
@@ -160,7 +160,8 @@ class FeedForward(nn.Module):
             # up projection (deferred adapter) -> GEGLU applying it -> down projection, one autograd node for the last two:
             # both adapters' wide read-modify-write passes disappear (kernels._GeGLUDown)
             return kernels.lora_geglu_down(hidden_states, up.linear, up.lora_down.weight, up.lora_up.weight, up._scale(),
-                                           down.linear, down.lora_down.weight, down.lora_up.weight, down._scale(), residual)
+                                           down.linear, down.lora_down.weight, down.lora_up.weight, down._scale(), residual,
+                                           up_pack=up.__dict__.get("_vft_pack"), down_pack=down.__dict__.get("_vft_pack"))
         return _proj_residual(self.net[2], self.net[1](self.net[0](hidden_states)), residual)
 
 

@@ -57,6 +57,69 @@ def replace_to_peft_layer(
         for _, m in model.named_modules():
             m.requires_grad_(False)
     _inject(model, config, targets, "")
+    install_adapter_pack(model)
+
+
+def build_adapter_pack(model: nn.Module):
+    """One `kernels.AdapterPack` for every bf16 LoRALinear of `model` that runs on the fused projection GEMM, plus one
+    grouped entry per attention module whose q/k/v projections are fused (duck-typed: `to_q`, `to_k`, `to_v` LoRALinears
+    and a `_fused_qkv_weight` method — SDXL SelfAttention).  Entries are attached to the modules (`_vft_pack`,
+    `_vft_qkv_pack`), which pass them to the kernels."""
+    from ... import kernels
+
+    loras = [m for m in model.modules() if isinstance(m, LoRALinear)]
+    dev = next((m.lora_down.weight.device for m in loras), None)
+    if dev is None or dev.type != "cuda":
+        return None
+    pack = kernels.AdapterPack(dev)
+    for m in loras:
+        base = m.linear
+        bf16_base = type(base) is nn.Linear and kernels.fused_lora_eligible(base.weight, m.rank)
+        nf4_base = (hasattr(base, "quant_state") and m.rank in (4, 8, 16) and base.in_features % 64 == 0
+                    and base.out_features % 64 == 0)  # the two cases kernels.lora_linear runs on a fused GEMM
+        if ((bf16_base or nf4_base) and m.lora_up.bias is None and m.lora_down.weight.dtype == torch.bfloat16
+                and m.lora_down.weight.device == dev):
+            m._vft_pack = pack.add([(m.lora_down.weight, m.lora_up.weight)], kernels._ext_rank(m.rank))
+    for mod in model.modules():
+        ps = [getattr(mod, n, None) for n in ("to_q", "to_k", "to_v")]
+        if callable(getattr(mod, "_fused_qkv_weight", None)) and all(isinstance(p_, LoRALinear) and hasattr(p_, "_vft_pack") for p_ in ps):
+            if len({p_.rank for p_ in ps}) == 1 and len({p_.lora_up.weight.shape for p_ in ps}) == 1 and 3 * ps[0].rank <= 16:
+                mod._vft_qkv_pack = pack.add([(p_.lora_down.weight, p_.lora_up.weight) for p_ in ps], kernels._ext_rank(3 * ps[0].rank))
+    if not pack.entries:
+        return None
+    pack.finalize()
+    return pack
+
+
+def _pack_pre_forward(model: nn.Module, args, kwargs=None):
+    state = model.__dict__.setdefault("_vft_pack_state", {"pack": None, "tried": False})
+    if state["pack"] is None and not state["tried"]:
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            state["pack"] = build_adapter_pack(model)
+            state["tried"] = state["pack"] is not None or any(
+                isinstance(m, LoRALinear) and m.lora_down.weight.is_cuda for m in model.modules())
+    if state["pack"] is not None:
+        state["pack"].refresh()
+
+
+def install_adapter_pack(model: nn.Module) -> None:
+    """Refresh the adapter operand pack at the start of every forward of the smallest submodule that contains all LoRA
+    layers (the denoiser: the trainers call it directly — also from inside captured HIP graphs — not through the
+    task object that `replace_to_peft_layer` receives).  The pack is built lazily at the first CUDA forward."""
+    names = [n.split(".") for n, m in model.named_modules() if isinstance(m, LoRALinear)]
+    if not names:
+        return
+    common = names[0][:-1]
+    for parts in names[1:]:
+        k = 0
+        while k < len(common) and k < len(parts) - 1 and common[k] == parts[k]:
+            k += 1
+        common = common[:k]
+    root = model.get_submodule(".".join(common)) if common else model
+    root.__dict__["_vft_pack_state"] = {"pack": None, "tried": False}  # adapters changed: rebuild
+    if not root.__dict__.get("_vft_pack_hooked", False):
+        root.register_forward_pre_hook(_pack_pre_forward, with_kwargs=True)
+        root.__dict__["_vft_pack_hooked"] = True
 
 
 def get_adapter_parameters(model: nn.Module) -> dict[str, torch.Tensor]:
@@ -98,6 +161,7 @@ def load_peft_weight(model: nn.Module, state_dict: dict[str, torch.Tensor]) -> N
     if detect_peft_method(state_dict) == "none":
         raise ValueError("Failed to detect peft method from state_dict")
     _load_into(model, state_dict, "")
+    install_adapter_pack(model)  # parameters were replaced
 
 
 class TrainableParameters(NamedTuple):

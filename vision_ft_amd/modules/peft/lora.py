@@ -75,7 +75,8 @@ class LoRALinear(PeftLayer):
             return y if residual is None else residual + y
         drop = self.dropout(x)
         if drop is x and self.lora_up.bias is None:
-            return kernels.lora_linear(x, self.linear, self.lora_down.weight, self.lora_up.weight, self._scale(), residual)
+            return kernels.lora_linear(x, self.linear, self.lora_down.weight, self.lora_up.weight, self._scale(), residual,
+                                       pack=self.__dict__.get("_vft_pack"))
         # dropout / adapter-bias variants are not on the benchmarked path: unfused but same math
         base = self.linear(x)
         lo = self.lora_up(self.lora_down(drop))
