@@ -213,3 +213,29 @@ def test_group_norm_is_bit_reproducible(gpu, nhwc):
     assert rel_err(runs[0][0].float(), ref) < 6e-3
     assert rel_err(runs[0][1].float(), xf.grad) < 1e-2
     assert rel_err(runs[0][2].float(), wf.grad) < 1e-2 and rel_err(runs[0][3].float(), bf.grad) < 1e-2
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 640, 320, 32, 24), (3, 1920, 640, 16, 16), (1, 960, 320, 20, 36)])
+def test_conv1x1_with_fused_add(gpu, B, Cin, Cout, H, W):
+    """ResidualBlock's skip convolution + `h + skip(x)` as one projection-GEMM launch (channels-last), forward, data
+    gradient, weight / bias gradients and the add's gradient, against fp32 math on the same bf16 operands."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator(device=gpu).manual_seed(B * 100 + Cin)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu).to(torch.bfloat16)  # noqa: E731
+    x = rn(B, Cin, H, W).contiguous(memory_format=torch.channels_last).requires_grad_()
+    h = rn(B, Cout, H, W).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (rn(Cout, Cin, 1, 1) * Cin ** -0.5).requires_grad_()
+    b = rn(Cout).requires_grad_()
+    dy = rn(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    assert kernels.conv1x1_eligible(x, w, (1, 1), (0, 0), (1, 1), 1)
+    y = kernels.conv1x1(x, w, b, add=h)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    xf, hf, wf, bf = (t.detach().float().requires_grad_() for t in (x, h, w, b))
+    ref = hf + F.conv2d(xf, wf, bf)
+    ref.backward(dy.float())
+    assert rel_err(y.float(), ref) < 6e-3
+    assert rel_err(x.grad.float(), xf.grad) < 6e-3
+    assert rel_err(w.grad.float(), wf.grad) < 1e-2 and rel_err(b.grad.float(), bf.grad) < 1e-2
+    assert torch.equal(h.grad, dy)

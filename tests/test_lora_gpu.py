@@ -271,7 +271,7 @@ def test_lora_geglu_down_fused_feedforward(gpu, M, C, r):
         assert rel_err(u, v.float()) < 1.2e-2, (i, rel_err(u, v.float()))
 
 
-def test_adapter_pack_forms_and_in_place_gradients(gpu):
+def test_adapter_pack_forms_and_in_place_gradients(gpu, lora_path):
     """One `vft_lora_pack` launch builds the operand forms of every adapter (transposes; the concatenated /
     block-diagonal / zero-padded forms of a fused q|k|v) exactly; with gradient tensors in place the weight-gradient
     kernel adds into them (what AccumulateGrad does with a returned gradient) and autograd gets None."""
@@ -319,7 +319,8 @@ def test_adapter_pack_forms_and_in_place_gradients(gpu):
     held_a, held_b = Aq.grad.clone(), Bq.grad.clone()
     y.backward(dy)
     after = kernels.PACK_STATS
-    assert after["pack_hit"] == before["pack_hit"] + 1 and after["grad_in_place"] == before["grad_in_place"] + 1
+    if lora_path == "gemm_fused":  # (the round-1 composition neither uses the pack nor writes gradients in place)
+        assert after["pack_hit"] == before["pack_hit"] + 1 and after["grad_in_place"] == before["grad_in_place"] + 1
     assert rel_err(Aq.grad.float(), held_a.float() + dA_ret.float()) < 4e-3
     assert rel_err(Bq.grad.float(), held_b.float() + dB_ret.float()) < 4e-3
     # fused q|k|v: three adapters' gradients from one grouped launch, in place, against the returned form

@@ -47,6 +47,23 @@ def lora():
               f"{bbwd/tb/1e9:7.0f} GB/s | wgrad2 {tw*1e6:7.1f} us {bwg/tw/1e9:7.0f} GB/s")
 
 
+def lora_down():
+    print("== vft_lora_down (t = x A^T) and vft_lora_wgrad2g at the bench shapes; GB/s of algorithmic bytes ==")
+    shapes = [(98304, 640, 4), (98304, 640, 16), (98304, 1920, 16), (98304, 2560, 4), (98304, 5120, 4), (24576, 1280, 4),
+              (24576, 1280, 16), (24576, 3840, 16), (24576, 5120, 4), (24576, 10240, 4), (17440, 3072, 16), (17440, 8192, 16)]
+    for M, K, r in shapes:
+        x, A = bf(M, K), bf(r, K)
+        t = timeit(lambda: kernels.lora_down(x, A, 0.25))
+        print(f"lora_down M={M:6d} K={K:5d} r={r:2d}: {t * 1e6:7.1f} us  {2.0 * M * K / t / 1e9:7.0f} GB/s")
+    for M, K, N, r in [(98304, 640, 640, 4), (98304, 640, 1920, 16), (98304, 640, 5120, 4), (98304, 2560, 640, 4),
+                       (24576, 1280, 1280, 4), (24576, 1280, 3840, 16), (24576, 1280, 10240, 4), (24576, 5120, 1280, 4),
+                       (17440, 3072, 3072, 16), (17440, 3072, 8192, 16), (17440, 8192, 3072, 16)]:
+        x, dy, u, tt = bf(M, K), bf(M, N), bf(M, r), bf(M, r)
+        A, B = bf(r, K).requires_grad_(), bf(N, r).requires_grad_()
+        t = timeit(lambda: kernels._lora_wgrad_into(x, u, dy, tt, [(A, B)], r, r, 1.0))
+        print(f"wgrad2g  M={M:6d} K={K:5d} N={N:5d} r={r:2d}: {t * 1e6:7.1f} us  {2.0 * M * (K + N) / t / 1e9:7.0f} GB/s")
+
+
 def attn():
     from vision_ft_amd import _C
 
@@ -202,6 +219,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("lora", "all"):
         lora()
+    if which in ("lora_down", "all"):
+        lora_down()
     if which in ("attn", "all"):
         attn()
     if which in ("norm", "all"):

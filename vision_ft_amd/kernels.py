@@ -1357,6 +1357,72 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, db
 
 
+def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) channels-last -> its (B*H*W, C) token matrix (a view)."""
+    x = x.contiguous(memory_format=torch.channels_last)
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+
+
+def conv1x1_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0)
+
+
+class _Conv1x1(torch.autograd.Function):
+    """add + conv1x1(x): on channels-last storage a 1x1 convolution is the projection GEMM over the pixel rows, so the
+    ResidualBlock's skip convolution and its `h + skip(x)` add (src/models/sdxl/denoiser.py:553-586) are one
+    vft_linear_fwd launch (bias and the add in the epilogue); the data gradient is the same call on the transposed weight."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, add):
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        x2 = _nhwc_rows(x)
+        w2 = weight.reshape(Cout, Cin)
+        a2 = _nhwc_rows(add) if add is not None else None
+        y = torch.empty((B, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        linear_fused(x2, w2, _bf16_or_none(bias), residual=a2, out=y.permute(0, 2, 3, 1).reshape(-1, Cout))
+        ctx.save_for_backward(x2, weight)
+        ctx.shape, ctx.has_bias, ctx.has_add = (B, Cin, H, W), bias is not None, add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        B, Cin, H, W = ctx.shape
+        Cout = weight.shape[0]
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dy2 = dy.permute(0, 2, 3, 1).reshape(-1, Cout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+            wt = weight.detach().reshape(Cout, Cin).t().contiguous() if weight.requires_grad else _conv1x1_wt(weight)
+            linear_fused(dy2, wt, None, out=dx.permute(0, 2, 3, 1).reshape(-1, Cin))
+        if ctx.needs_input_grad[1]:  # full fine-tune: plain library GEMM over the pixels
+            dw = (dy2.t() @ x2).reshape(weight.shape).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.float().sum(0).to(dy.dtype)
+        return dx, dw, db, (dy if ctx.has_add and ctx.needs_input_grad[3] else None)
+
+
+def _conv1x1_wt(weight: torch.Tensor) -> torch.Tensor:
+    """(Cin, Cout) transpose of a frozen 1x1 convolution weight, cached on the parameter."""
+    hit = getattr(weight, "_vft_wt", None)
+    if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
+        hit = (weight._version, weight.data_ptr(), weight.detach().reshape(weight.shape[0], weight.shape[1]).t().contiguous())
+        if not torch.cuda.is_current_stream_capturing():
+            weight._vft_wt = hit
+    return hit[2]
+
+
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, add: torch.Tensor | None = None) -> torch.Tensor:
+    """add + 1x1 / stride 1 convolution of a (B,Cin,H,W) tensor, channels-last in and out (Cin, Cout multiples of 64)."""
+    _ready(x, weight)
+    _require_gpu(x, weight, bias)
+    return _Conv1x1.apply(x, weight, bias, add)
+
+
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     """3x3 / stride 1 / padding 1 convolution of a (B,Cin,H,W) tensor, channels-last in and out."""
     _ready(x, weight)

@@ -225,6 +225,8 @@ class _Conv2d(nn.Conv2d):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if kernels.conv3x3_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return kernels.conv3x3(x, self.weight, self.bias)
+        if kernels.conv1x1_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            return kernels.conv1x1(x, self.weight, self.bias)
         return super().forward(x)
 
 
@@ -357,7 +359,11 @@ class ResidualBlock(nn.Module):
         h = h + emb.view(emb.shape[0], emb.shape[1], 1, 1)
         h = self.out_layers[0](h)  # GroupNorm + SiLU (fused)
         h = self.out_layers[3](self.out_layers[2](h))
-        return h + self.skip_connection(residual)
+        skip = self.skip_connection
+        if isinstance(skip, nn.Conv2d) and kernels.conv1x1_eligible(residual, skip.weight, skip.stride, skip.padding,
+                                                                    skip.dilation, skip.groups):
+            return kernels.conv1x1(residual, skip.weight, skip.bias, add=h)  # the add rides in the GEMM's epilogue
+        return h + skip(residual)
 
 
 def _forward_layer(layer: nn.Module, *args, gradient_checkpointing: bool = False, use_reentrant: bool = False):
