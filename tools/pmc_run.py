@@ -5,7 +5,9 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vision_ft_amd import kernels  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -11,6 +11,8 @@ ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
     "attn_fwd_kernel": 4 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "attn_bwd_dq_kernel": 5 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "attn_bwd_dkdv_kernel": 6 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "attn_bwd_dq3_kernel": 5 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "attn_bwd_dkdv3_kernel": 6 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "lora_rows_kernelILi4ELb1": (2 * 98304 * 640 + 4 * 98304 * 5120) / 1e6,
     "lora_rows_kernelILi4ELb0": (2 * 98304 * 5120 + 4 * 98304 * 640) / 1e6,
     "lora_wgrad_partial": 2 * 98304 * (640 + 5120) / 1e6,
@@ -33,7 +35,7 @@ def per_kernel(d, counter):
             continue
         name = r["Kernel_Name"]
         if "lin8_kernel" in name:  # plain launches: 3 of the first shape, then 3 of the second; conv launches: Lb1 in the template
-            conv = "ELb1EE" in name
+            conv = "ELb1EE" in name or ", true>" in name
             key = "lin8_conv" if conv else ("lin8_kernel" if lin8_seen < 3 else "lin8_kernel_b")
             lin8_seen += 0 if conv else 1
             acc[key] += float(r["Counter_Value"])
