@@ -378,7 +378,9 @@ struct DmaTile {
     static constexpr int OOBV = (int)0x80000000u;
     // rows [row0, row0 + ROWS) of the tensor behind `rs` (row stride in elements); rows >= row_limit read zeros
     static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int row0, int row_limit, int row_stride_elems) {
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));  // not hoisted out of the caller's loop and kept there: recomputed at every issue
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int byte = (wv * NI + q) * 1024 + lane * 16;
@@ -446,16 +448,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
         vbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;  // ^ ((dt & 3) << 6), + (dt >> 2) * 256, + kk * 16 * RB
     }
 
-    for (int t = 0; t < ntiles; ++t) {
+    // The two wave groups (g = 0: waves 0-3, g = 1: waves 4-7; a SIMD holds one wave of each) run HALF A TILE APART:
+    //     phase A(t):  g0  S = K(t) Q^T            | g1  softmax + O += V(t-1)^T P^T
+    //     phase B(t):  g0  softmax + O += V(t)^T P | g1  S = K(t) Q^T
+    // so in every phase one wave of a SIMD starts on the matrix pipe while its partner is in the softmax's VALU work,
+    // instead of both waves doing the same thing at the same time (two waves in lockstep share the pipe they both want
+    // and leave the other one idle).  K(t+1) is issued at the start of phase A(t) (its buffer's last reader, g1's S of
+    // tile t-1, ended with phase B(t-1)), V(t+1) at the start of phase B(t) (last reader: g1's PV of tile t-1 in phase
+    // A(t)); a wave's DMAs retire in order, so the counted vmcnt before each barrier leaves the younger tile in flight.
+    f32x16 S;
+    auto qk = [&](int t) {  // S^T[key][q] = K Q^T for this wave's 32 keys of tile t
         const char* Kc = smem + (t & 1) * 2 * TILE;
-        const char* Vc = Kc + TILE;
-        if (t + 1 < ntiles) {  // the other buffer was last read before the barrier that ended tile t-1
-            char* Kn = smem + ((t + 1) & 1) * 2 * TILE;
-            Stage::issue(rk, Kn, (t + 1) * 64, kvl, ks_s);
-            Stage::issue(rv, Kn + TILE, (t + 1) * 64, kvl, vs_s);
-        }
-        // S^T[key][q] = K Q^T for this wave's 32 keys
-        f32x16 S;
 #pragma unroll
         for (int i = 0; i < 16; ++i) S[i] = 0.f;
 #pragma unroll
@@ -463,15 +466,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kc + ((kbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256));
             S = mfma32(a, Qf[ks], S);
         }
-        const int n0 = t * 64 + 32 * g;
         if (t * 64 + 64 > kvl) {  // block-uniform: only the last key tile can be ragged
-            asm volatile("; ragged tail tile" ::: "memory");
+            const int n0 = t * 64 + 32 * g;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = n0 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (key >= kvl) S[i] = -INFINITY;
             }
         }
+    };
+    auto softmax_pv = [&](int t) {
+        const char* Vc = smem + (t & 1) * 2 * TILE + TILE;
         float tmax = S[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, S[i]);
@@ -513,9 +518,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
                 s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 O[dt] = mfma32(__builtin_bit_cast(bf16x8, both), Pf[kk], O[dt]);
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (issued a whole tile of compute ago)
-        __builtin_amdgcn_s_barrier();
+    };
+    constexpr int NI = Stage::NI;
+    // Each group issues its share of a DMA where its own S is dead (g0: before its QK^T / after its PV; g1: after its PV /
+    // before its QK^T) — S live across an issue costs 16 registers this kernel does not have at head_dim 256.
+    auto wait_older = [&](bool two_in_flight) {  // all but this phase's own (younger) tile have landed
+        if (two_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (g == 0) {
+        for (int t = 0; t < ntiles; ++t) {
+            const bool next = t + 1 < ntiles;
+            if (next) Stage::issue(rk, smem + ((t + 1) & 1) * 2 * TILE, (t + 1) * 64, kvl, ks_s);
+            qk(t);
+            wait_older(next);  // V(t)
+            __builtin_amdgcn_s_barrier();
+            softmax_pv(t);
+            if (next) Stage::issue(rv, smem + ((t + 1) & 1) * 2 * TILE + TILE, (t + 1) * 64, kvl, vs_s);
+            wait_older(next);  // K(t+1)
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) {
+            const bool next = t + 1 < ntiles;
+            if (t > 0) softmax_pv(t - 1);
+            if (next) Stage::issue(rk, smem + ((t + 1) & 1) * 2 * TILE, (t + 1) * 64, kvl, ks_s);
+            wait_older(next);
+            __builtin_amdgcn_s_barrier();
+            if (next) Stage::issue(rv, smem + ((t + 1) & 1) * 2 * TILE + TILE, (t + 1) * 64, kvl, vs_s);
+            qk(t);
+            wait_older(next);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (ntiles > 0) softmax_pv(ntiles - 1);
     }
+    __syncthreads();  // (g1 leaves the loop one phase after g0: the merge below re-uses the K/V buffers)
 
     // ---- merge the wave pair: wave g finalises d-tiles [g DT/2, (g+1) DT/2); it receives the partner's accumulators for
     //      those tiles (and the partner's m, l) through the K/V buffers, which are idle now ------------------------------

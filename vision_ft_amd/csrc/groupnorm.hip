@@ -81,18 +81,35 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     out[i] = v;
 }
 
-// affine gradients: dw[c] = Σ_blk cpart[blk][0][c], db[c] = Σ_blk cpart[blk][1][c], blocks in index order
+// affine gradients: dw[c] = Σ_blk cpart[blk][0][c], db[c] = Σ_blk cpart[blk][1][c].  A workgroup owns 32 channels; its 8
+// thread rows each add a contiguous slice of the blocks in index order, then the 8 slice sums are added in slice
+// order: a fixed association for a given (nblk, C), hence deterministic, with 8x the parallelism of one thread per channel
 __global__ __launch_bounds__(256) void gn_finalize_affine_kernel(const float* __restrict__ cpart, float* __restrict__ dw,
                                                                  float* __restrict__ db, int nblk, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int per = (nblk + 7) / 8;
+    const int j0 = sl * per, j1 = min(nblk, j0 + per);
     float a = 0.f, b = 0.f;
-    for (int j = 0; j < nblk; ++j) {
-        a += cpart[((int64_t)j * 2) * C + c];
-        b += cpart[((int64_t)j * 2 + 1) * C + c];
+    if (c < C)
+        for (int j = j0; j < j1; ++j) {
+            a += cpart[((int64_t)j * 2) * C + c];
+            b += cpart[((int64_t)j * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = a;
+    red[1][sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sa += red[0][q][cl];
+            sb += red[1][q][cl];
+        }
+        if (dw) dw[c] = sa;
+        if (db) db[c] = sb;
     }
-    if (dw) dw[c] = a;
-    if (db) db[c] = b;
 }
 
 template <int V>
@@ -573,7 +590,7 @@ extern "C" int vft_groupnorm_bwd(const void* x, const void* dy, const float* sta
     }
 #undef VFT_GN_BWD
     if (affine)
-        hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cpart, dweight, dbias, N, C);
+        hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3((C + 31) / 32), dim3(256), 0, st, cpart, dweight, dbias, N, C);
     VFT_CHECK_LAUNCH("vft_groupnorm_bwd");
     return 0;
 }
@@ -615,7 +632,7 @@ extern "C" int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float
                        fuse_silu);
     finalize_groups(scratch, bstats, (int64_t)N * G, (int)grid.x, st);
     if (affine)
-        hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, st, cpart, dweight, dbias,
+        hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3((C + 31) / 32), dim3(256), 0, st, cpart, dweight, dbias,
                            (int)(N * grid.x), C);
     hipLaunchKernelGGL(gn_nhwc_bwd_dx_kernel, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats,
                        (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)dx, gm, eps, fuse_silu);
