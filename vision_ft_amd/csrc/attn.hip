@@ -378,9 +378,7 @@ struct DmaTile {
     static constexpr int OOBV = (int)0x80000000u;
     // rows [row0, row0 + ROWS) of the tensor behind `rs` (row stride in elements); rows >= row_limit read zeros
     static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int row0, int row_limit, int row_stride_elems) {
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        int lane = threadIdx.x & 63;
-        asm volatile("" : "+v"(lane));  // not hoisted out of the caller's loop and kept there: recomputed at every issue
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int byte = (wv * NI + q) * 1024 + lane * 16;
@@ -394,6 +392,181 @@ struct DmaTile {
 
 template <int D>
 __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;  // bytes of one K (or V) tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), qg = w & 3, g = w >> 2;
+    int qtile, bh;
+    if (!xcd_map((p.Sq + 127) / 128, p.B * p.Hq, qtile, bh)) return;  // block-uniform
+    const int b = bh / p.Hq, hq = bh % p.Hq, q0 = qtile * 128;
+    const int hkv = hq / (p.Hq / p.Hkv);
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* Ob = p.o + b * p.so.b + hq * p.so.h;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((int64_t)(p.Sk - 1) * p.sk.s + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((int64_t)(p.Sk - 1) * p.sv.s + D) * 2), 0x00020000);
+
+    const int qrow = q0 + qg * 32 + r;
+    const bool qok = qrow < p.Sq;
+    bf16x8 Qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+    const float sc = p.scale * kLog2e;
+
+    const int ntiles = (kvl + 63) / 64;
+    typedef DmaTile<D, 64> Stage;
+    const int ks_s = (int)p.sk.s, vs_s = (int)p.sv.s;
+    if (ntiles > 0) {
+        Stage::issue(rk, smem, 0, kvl, ks_s);
+        Stage::issue(rv, smem + TILE, 0, kvl, vs_s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses of this lane (bytes inside a tile).  K rows: row 32 g + r, chunk 2 ks + h;
+    // V transposed: rows 32 g + 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
+    const int krow = 32 * g + r;
+    const int kbase = krow * RB + ((h ^ swz_f<RB>(krow)) << 4);  // ^ ((ks & 7) << 5), + (ks >> 3) * 256
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int vbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 32 * g + 4 * h + (i16 >> 2) + 8 * hi;
+        vbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;  // ^ ((dt & 3) << 6), + (dt >> 2) * 256, + kk * 16 * RB
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const char* Kc = smem + (t & 1) * 2 * TILE;
+        const char* Vc = Kc + TILE;
+        if (t + 1 < ntiles) {  // the other buffer was last read before the barrier that ended tile t-1
+            char* Kn = smem + ((t + 1) & 1) * 2 * TILE;
+            Stage::issue(rk, Kn, (t + 1) * 64, kvl, ks_s);
+            Stage::issue(rv, Kn + TILE, (t + 1) * 64, kvl, vs_s);
+        }
+        // S^T[key][q] = K Q^T for this wave's 32 keys
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kc + ((kbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256));
+            S = mfma32(a, Qf[ks], S);
+        }
+        const int n0 = t * 64 + 32 * g;
+        if (t * 64 + 64 > kvl) {  // block-uniform: only the last key tile can be ragged
+            asm volatile("; ragged tail tile" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = n0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key >= kvl) S[i] = -INFINITY;
+            }
+        }
+        float tmax = S[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, S[i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        // Lazy rescale: the reference exponent m only follows the running maximum when it has grown by more than 2^8
+        // (P then stays below 256: nothing for bf16 / fp32 accumulation), so the D/2-register rescale of O — as much
+        // VALU work as the tile's softmax — runs in the first tiles only instead of in most of them (with 32 queries per
+        // wave SOME row sets a new maximum in nearly every tile).  m, l and O stay mutually consistent, so the result is
+        // the same softmax; the pair merge and the LSE use m as it is.
+        const float ts = tmax * sc;
+        const float m_new = ts > m + 8.f ? ts : m;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pv = __builtin_amdgcn_exp2f(S[i] * sc - m_new);
+            psum += pv;
+            S[i] = pv;
+        }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // exact skip once the running maxima have settled
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+        }
+        bf16x8 Pf[2];
+        Pf[0] = pack8(S, 0);
+        Pf[1] = pack8(S, 1);
+        // O^T[d][q] += V^T P^T over this wave's 32 keys
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const char* a0 = Vc + kk * 16 * RB + (dt >> 2) * 256;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (vbase[0] ^ ((dt & 3) << 6))));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (vbase[1] ^ ((dt & 3) << 6))));
+                s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                O[dt] = mfma32(__builtin_bit_cast(bf16x8, both), Pf[kk], O[dt]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (issued a whole tile of compute ago)
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- merge the wave pair: wave g finalises d-tiles [g DT/2, (g+1) DT/2); it receives the partner's accumulators for
+    //      those tiles (and the partner's m, l) through the K/V buffers, which are idle now ------------------------------
+    constexpr int HT = DT / 2;
+    float4* X = reinterpret_cast<float4*>(smem);           // [8 waves][HT*4 float4][64 lanes]
+    float2* ML = reinterpret_cast<float2*>(smem + 8 * HT * 4 * 64 * 16);  // [8 waves][64 lanes]
+    const float ltot_own = lsum + __shfl_xor(lsum, 32, 64);
+    // (register arrays must be indexed by compile-time constants: the two roles are separate code paths)
+    auto give = [&](auto GIVE0) {  // write the accumulators of the partner's d-tiles
+        constexpr int base = decltype(GIVE0)::value * HT;
+#pragma unroll
+        for (int j = 0; j < HT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                X[(w * HT * 4 + j * 4 + e) * 64 + lane] =
+                    make_float4(O[base + j][4 * e], O[base + j][4 * e + 1], O[base + j][4 * e + 2], O[base + j][4 * e + 3]);
+    };
+    if (g == 0) give(std::integral_constant<int, 1>{}); else give(std::integral_constant<int, 0>{});
+    ML[w * 64 + lane] = make_float2(m, ltot_own);
+    __syncthreads();
+    const int pw = w ^ 4;
+    const float2 pml = ML[pw * 64 + lane];
+    const float mm = fmaxf(m, pml.x);
+    const float a_own = __builtin_amdgcn_exp2f(m - mm), a_par = __builtin_amdgcn_exp2f(pml.x - mm);
+    const float ltot = ltot_own * a_own + pml.y * a_par;
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    auto take = [&](auto MINE) {  // combine, normalise and store this wave's d-tiles
+        constexpr int base = decltype(MINE)::value * HT;
+#pragma unroll
+        for (int j = 0; j < HT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 po = X[(pw * HT * 4 + j * 4 + e) * 64 + lane];
+                bf16_t* dst = Ob + (int64_t)qrow * p.so.s + (base + j) * 32 + 8 * e + 4 * h;
+                store4(dst, (O[base + j][4 * e] * a_own + po.x * a_par) * inv, (O[base + j][4 * e + 1] * a_own + po.y * a_par) * inv,
+                       (O[base + j][4 * e + 2] * a_own + po.z * a_par) * inv, (O[base + j][4 * e + 3] * a_own + po.w * a_par) * inv);
+            }
+    };
+    if (qok) {
+        if (g == 0) take(std::integral_constant<int, 0>{}); else take(std::integral_constant<int, 1>{});
+        if (g == 0 && h == 0 && p.lse) {
+            p.lse[((int64_t)b * p.Hq + hq) * p.Sq + qrow] = ltot > 0.f ? (mm + __log2f(ltot)) * kLn2 : -INFINITY;
+        }
+    }
+}
+
+// Staggered form of attn_fwd2_kernel (same tiling, LDS image and pair merge): measured on MI355X it is 14-15 % faster at
+// head_dim 128 (574 -> 655-663 TF/s, B16 H16 S2048) and 13 % SLOWER at head_dim 256, where the second copy of the loop body
+// costs 24 spilled registers (728 -> 617 TF/s) — so it serves head_dim 128 only.
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_fwd2s_kernel(AttnParams p) {
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;  // bytes of one K (or V) tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -1667,13 +1840,15 @@ int launch_fwd2(const AttnParams& p, hipStream_t st) {
     // two K/V buffers (they also carry the pair merge: 8 x D/4 float4 x 64 lanes = the same bytes) + the pair's m / l
     constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t) + 8 * 64 * sizeof(float2);
     static_assert(8 * (D / 64) * 4 * 64 * 16 <= 2 * 2 * 64 * D * 2, "merge area");
+    // head_dim 128 runs the staggered schedule (+14 %), head_dim 256 the lockstep one (the staggered body spills there)
+    auto* kern = D == 128 ? attn_fwd2s_kernel<D> : attn_fwd2_kernel<D>;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid(xcd_grid((p.Sq + 127) / 128, p.B * p.Hq));
-    hipLaunchKernelGGL(attn_fwd2_kernel<D>, grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
     VFT_CHECK_LAUNCH("vft_attn_fwd");
     return 0;
 }
