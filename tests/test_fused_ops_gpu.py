@@ -239,3 +239,31 @@ def test_conv1x1_with_fused_add(gpu, B, Cin, Cout, H, W):
     assert rel_err(x.grad.float(), xf.grad) < 6e-3
     assert rel_err(w.grad.float(), wf.grad) < 1e-2 and rel_err(b.grad.float(), bf.grad) < 1e-2
     assert torch.equal(h.grad, dy)
+
+
+def test_plain_linear_on_the_fused_gemm(gpu):
+    """kernels.linear: residual + x W^T + b with the data gradient on the same kernel; the weight / bias gradients
+    accumulate into existing gradient tensors (flat-buffer views) or are returned."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator(device=gpu).manual_seed(9)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu).to(torch.bfloat16)  # noqa: E731
+    x = rn(4, 520, 640).requires_grad_()
+    res = rn(4, 520, 1280).requires_grad_()
+    w = (rn(1280, 640) * 640 ** -0.5).requires_grad_()
+    b = rn(1280).requires_grad_()
+    dy = rn(4, 520, 1280)
+    assert kernels.linear_eligible(x, w)
+    y = kernels.linear(x, w, b, res)
+    gx, gw, gb, gr = torch.autograd.grad(y, (x, w, b, res), dy, retain_graph=True)
+    xf, wf, bf, rf = (t.detach().float().requires_grad_() for t in (x, w, b, res))
+    ref = rf + F.linear(xf, wf, bf)
+    ref.backward(dy.float())
+    assert rel_err(y.float(), ref) < 6e-3 and rel_err(gx.float(), xf.grad) < 6e-3
+    assert rel_err(gw.float(), wf.grad) < 1e-2 and rel_err(gb.float(), bf.grad) < 1e-2 and torch.equal(gr, dy)
+    # in-place accumulation into existing gradient tensors
+    w.grad, b.grad = rn(1280, 640) * 0.1, rn(1280) * 0.1
+    hw, hb = w.grad.clone(), b.grad.clone()
+    y.backward(dy)
+    assert rel_err(w.grad.float(), hw.float() + wf.grad) < 1e-2
+    assert rel_err(b.grad.float(), hb.float() + bf.grad) < 1e-2

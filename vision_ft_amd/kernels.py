@@ -1291,6 +1291,66 @@ def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
 
 
 # =============================================================================================
+# plain (trainable or frozen) projection on the fused GEMM: full fine-tuning and the non-adapted Linears
+# =============================================================================================
+def linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """nn.Linear calls the projection GEMM takes: bf16 on the GPU, in_features a multiple of 64, out_features of 8, and
+    enough rows for the 128-row tiles to matter (tiny conditioning MLPs stay on the library)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and x.numel() // x.shape[-1] >= 1024)
+
+
+class _Linear(torch.autograd.Function):
+    """residual + x W^T + b on vft_linear_fwd (bias and the skip add in the epilogue) with the data gradient on the same
+    kernel (nn.Linear of every projection the reference builds, e.g. src/models/sdxl/denoiser.py:62-64,183-204).  The
+    weight gradient is a plain library GEMM that ACCUMULATES straight into the parameter's gradient tensor when there is
+    one (the trainer's flat buffer): no separate accumulation pass per parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        x2 = _rows(x)
+        res2 = _bf16_rows(residual)
+        with torch.cuda.device(x.device):
+            y2 = linear_fused(x2, weight, _bf16_or_none(bias), residual=res2)
+        ctx.save_for_backward(x2, weight)
+        ctx.params = (weight, bias)
+        ctx.xshape = x.shape
+        ctx.res_shape = residual.shape if residual is not None else None
+        return y2.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        wparam, bparam = ctx.params
+        dy2 = _bf16_rows(dy)
+        dx = dw = db = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[0]:
+                dx = linear_fused(dy2, _transposed_weight(weight), None).view(ctx.xshape)
+            if ctx.needs_input_grad[1]:
+                g = _grad_target(wparam)
+                if g is not None:
+                    g.addmm_(dy2.t(), x2)  # beta = 1: accumulate in place
+                else:
+                    dw = dy2.t() @ x2
+            if bparam is not None and ctx.needs_input_grad[2]:
+                gb = _grad_target(bparam)
+                if gb is not None:
+                    gb.add_(dy2.sum(0, dtype=torch.float32))
+                else:
+                    db = dy2.sum(0, dtype=torch.float32).to(bparam.dtype)
+        dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, residual: torch.Tensor | None = None) -> torch.Tensor:
+    """residual + F.linear(x, weight, bias) on the fused projection GEMM (see `linear_eligible`)."""
+    _ready(x, weight)
+    _require_gpu(x, weight, bias)
+    return _Linear.apply(x, weight, bias, residual)
+
+
+# =============================================================================================
 # 3x3 convolution (implicit GEMM on the fused-linear kernel), channels-last
 # =============================================================================================
 def conv3x3_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:

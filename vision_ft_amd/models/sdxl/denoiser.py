@@ -41,12 +41,17 @@ def _split_heads(t: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
 
 
 def _proj_residual(layer: nn.Module, h: torch.Tensor, residual: torch.Tensor | None) -> torch.Tensor:
-    """residual + layer(h); a LoRA-wrapped projection folds the add into its own kernel pass."""
-    if residual is None:
-        return layer(h)
+    """residual + layer(h); a LoRA-wrapped projection folds the add into its own kernel pass, a plain nn.Linear runs on
+    the fused projection GEMM (bias and the add in its epilogue)."""
     if isinstance(layer, LoRALinear):
-        return layer(h, residual=residual)
-    return residual + layer(h)
+        return layer(h) if residual is None else layer(h, residual=residual)
+    if type(layer) is nn.Linear and kernels.linear_eligible(h, layer.weight):
+        return kernels.linear(h, layer.weight, layer.bias, residual)
+    return layer(h) if residual is None else residual + layer(h)
+
+
+def _proj(layer: nn.Module, h: torch.Tensor) -> torch.Tensor:
+    return _proj_residual(layer, h, None)
 
 
 def _merge_heads(t: torch.Tensor) -> torch.Tensor:
@@ -90,9 +95,9 @@ class SelfAttention(nn.Module):
                                        [(p.lora_down.weight, p.lora_up.weight) for p in (self.to_q, self.to_k, self.to_v)],
                                        self.to_q._scale(), self.num_heads, pack=self.__dict__.get("_vft_qkv_pack"))
         else:
-            q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
-            k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)
-            v = _split_heads(self.to_v(hidden_states), self.num_heads, self.head_dim)
+            q = _split_heads(_proj(self.to_q, hidden_states), self.num_heads, self.head_dim)
+            k = _split_heads(_proj(self.to_k, hidden_states), self.num_heads, self.head_dim)
+            v = _split_heads(_proj(self.to_v, hidden_states), self.num_heads, self.head_dim)
         attn = scaled_dot_product_attention(q, k, v, mask=mask, backend=self.attn_implementation)
         return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
@@ -115,9 +120,9 @@ class CrossAttention(nn.Module):
 
     def forward(self, query: torch.Tensor, context: torch.Tensor, mask: torch.Tensor | None = None,
                 time_embedding: torch.Tensor | None = None, *args, residual: torch.Tensor | None = None, **kwargs) -> torch.Tensor:
-        q = _split_heads(self.to_q(query), self.num_heads, self.head_dim)
-        k = _split_heads(self.to_k(context), self.num_heads, self.head_dim)
-        v = _split_heads(self.to_v(context), self.num_heads, self.head_dim)
+        q = _split_heads(_proj(self.to_q, query), self.num_heads, self.head_dim)
+        k = _split_heads(_proj(self.to_k, context), self.num_heads, self.head_dim)
+        v = _split_heads(_proj(self.to_v, context), self.num_heads, self.head_dim)
         attn = scaled_dot_product_attention(q, k, v, mask=mask, backend=self.attn_implementation)
         return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
@@ -139,7 +144,7 @@ class GeGLU(nn.Module):
                 and kernels.lora_geglu_eligible(hidden_states, p.linear, p.lora_down.weight)):
             # the adapter's update is applied inside the GEGLU kernel: no extra pass over the (M, 8C) projection
             return kernels.lora_linear_geglu(hidden_states, p.linear, p.lora_down.weight, p.lora_up.weight, p._scale())
-        return kernels.geglu(p(hidden_states))
+        return kernels.geglu(_proj(p, hidden_states))
 
 
 class FeedForward(nn.Module):
@@ -264,13 +269,15 @@ class SpatialTransformer(nn.Module):
                 cross_attention_kwargs: dict | None = None) -> torch.Tensor:
         b, c, h, w = hidden_states.shape
         tokens = self.norm(hidden_states).permute(0, 2, 3, 1).reshape(b, h * w, c)
-        tokens = self.proj_in(tokens)
+        tokens = _proj(self.proj_in, tokens)
         extra = dict(transformer_args or {}, height=h, width=w)
         for block in self.transformer_blocks:
             tokens = block(tokens, context=context, time_embedding=time_embedding,
                            cross_attention_kwargs=cross_attention_kwargs, **extra)
-        tokens = self.proj_out(tokens)
-        return tokens.reshape(b, h, w, self.inner_dim).permute(0, 3, 1, 2) + hidden_states
+        # + hidden_states rides in proj_out's epilogue: on channels-last storage the skip's token view is free
+        skip = hidden_states.permute(0, 2, 3, 1).reshape(b, h * w, c)
+        tokens = _proj_residual(self.proj_out, tokens, skip)
+        return tokens.reshape(b, h, w, self.inner_dim).permute(0, 3, 1, 2)
 
 
 class Downsample(nn.Module):
