@@ -253,7 +253,7 @@ def test_plain_linear_on_the_fused_gemm(gpu):
     w = (rn(1280, 640) * 640 ** -0.5).requires_grad_()
     b = rn(1280).requires_grad_()
     dy = rn(4, 520, 1280)
-    assert kernels.linear_eligible(x, w)
+    assert kernels.linear_eligible(x, w.detach()) and not kernels.linear_eligible(x, w)  # frozen weights only by default
     y = kernels.linear(x, w, b, res)
     gx, gw, gb, gr = torch.autograd.grad(y, (x, w, b, res), dy, retain_graph=True)
     xf, wf, bf, rf = (t.detach().float().requires_grad_() for t in (x, w, b, res))

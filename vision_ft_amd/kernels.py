@@ -7,6 +7,7 @@ There is no CPU path: tensors that are not on a CUDA(HIP) device raise.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 
 import torch
@@ -1293,10 +1294,16 @@ def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
 # =============================================================================================
 # plain (trainable or frozen) projection on the fused GEMM: full fine-tuning and the non-adapted Linears
 # =============================================================================================
+PLAIN_LINEAR_GEMM = os.environ.get("VFT_PLAIN_LINEAR", "1") != "0"  # A/B switch: 0 = plain nn.Linear stays on the library
+
+
 def linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """nn.Linear calls the projection GEMM takes: bf16 on the GPU, in_features a multiple of 64, out_features of 8, and
-    enough rows for the 128-row tiles to matter (tiny conditioning MLPs stay on the library)."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
+    """nn.Linear calls the projection GEMM takes: FROZEN bf16 weights on the GPU (in_features a multiple of 64, out_features
+    of 8) and enough rows for the 128-row tiles to matter (tiny conditioning MLPs stay on the library).  Trainable weights
+    (full fine-tune) stay on the tuned library GEMMs: measured A/B on one MI355X, SDXL full fine-tune B=16 runs 27.4
+    images/s there and 26.1 here — the per-step transposes of 2.6 B weights for the data gradient and the table-tuned
+    library solutions outweigh the fused bias / skip epilogue."""
+    return (PLAIN_LINEAR_GEMM and not weight.requires_grad and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and x.numel() // x.shape[-1] >= 1024)
 
 
