@@ -283,3 +283,34 @@ def test_conv3x3_implicit_gemm(gpu, B, Cin, Cout, H, W, bias):
         xg2.grad = None
         kernels.conv3x3(xg2, wf, bg.detach() if bias else None).backward(gy.to(gpu))
         assert rel_err(xg2.grad.cpu(), xr.grad) < 5e-3
+
+
+def test_every_tile_variant_gives_the_same_bits(gpu):
+    """vft_linear_variant 1 / 2 / 3 (tile sizes) and 11 / 12 / 13 (whole rounds on that tile + the remaining rows as a second
+    launch on a smaller tile): the K order per output element does not depend on the tile, so the results are bit-identical —
+    for the GEMM with every epilogue input and for the implicit-GEMM convolution, whose first part must still read the halo
+    rows that belong to the second part (sizes with several rounds of 256 tile slots so that the split really splits)."""
+    from vision_ft_amd import _C, kernels
+
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 256 * 70 + 40, 3072, 640   # 71 x 12 = 852 tiles of 256x256: 3 whole rounds + a ragged one
+    x, w, b = _bf(g, M, K).to(gpu), _bf(g, N, K, sc=K**-0.5).to(gpu), _bf(g, N, sc=0.2).to(gpu)
+    rs, ex, ew = _bf(g, M, N).to(gpu), _bf(g, M, 4, sc=0.5).to(gpu), _bf(g, N, 4, sc=0.5).to(gpu)
+    xc = _bf(g, 3, 320, 96, 80).to(gpu).contiguous(memory_format=torch.channels_last)   # 23040 pixels x 640 outputs
+    wc = _bf(g, 640, 320, 3, 3, sc=(9 * 320) ** -0.5).to(gpu).contiguous(memory_format=torch.channels_last)
+    bc = _bf(g, 640, sc=0.2).to(gpu)
+    outs = {}
+    try:
+        for v in (1, 2, 3, 11, 12, 13):
+            assert _C.lib().vft_linear_variant(v) == 0
+            outs[v] = (kernels.linear_fused(x, w, b, rs, ex, ew), kernels._conv3x3_call(xc, wc, bc, 3, 96, 80, 320, 640, "conv3x3_fwd"))
+    finally:
+        _C.lib().vft_linear_variant(0)
+    for v in (2, 3, 11, 12, 13):
+        assert torch.equal(outs[v][0], outs[1][0]), v
+        assert torch.equal(outs[v][1], outs[1][1]), v
+    ref = (x.float() @ w.float().t() + b.float() + ex.float() @ ew.float().t()).to(torch.bfloat16).float() + rs.float()
+    assert rel_err(outs[11][0].float(), ref) < 5e-3
+    import torch.nn.functional as F
+    refc = F.conv2d(xc.float(), wc.float(), bc.float(), padding=1)
+    assert rel_err(outs[11][1].float(), refc) < 5e-3

@@ -522,8 +522,28 @@ int pick_tile(int M, int N, int K, int conv) {
 }
 }  // namespace
 
+// cfg 1..3: one launch on that tile; 11..13: whole rounds on tile cfg - 10, the remaining rows as a second launch
+static void launch_lin8_cfg(Lin8Params q, int cfg, bool conv, hipStream_t st) {
+    if (cfg >= 11) {
+        const int main_cfg = cfg - 10;
+        const int M1 = vft_lin8_split_rows(q.M, q.N, main_cfg);
+        if (M1 > 0) {
+            Lin8Params a = q, b = q;
+            a.M = M1;
+            a.x_rows = b.x_rows = q.M;
+            b.m_begin = M1;
+            vft_lin8_launch(a, main_cfg, conv, st);
+            vft_lin8_launch(b, vft_lin8_pick(q.M - M1, q.N, q.K), conv, st);
+            return;
+        }
+        cfg = main_cfg;
+    }
+    vft_lin8_launch(q, cfg, conv, st);
+}
+
 extern "C" int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg) {
-    VFT_CHECK_ARG(M > 0 && N > 0 && K > 0 && cfg >= 0 && cfg <= 3, "vft_linear_tile_hint: need M,N,K>0 and cfg in 0..3 (0 clears)");
+    VFT_CHECK_ARG(M > 0 && N > 0 && K > 0 && ((cfg >= 0 && cfg <= 3) || (cfg >= 11 && cfg <= 13)),
+                  "vft_linear_tile_hint: need M,N,K>0 and cfg in 0..3 or 11..13 (0 clears)");
     std::lock_guard<std::mutex> g(g_tile_mu);
     if (cfg == 0)
         g_tile_hints.erase(tile_key(M, N, K, conv));
@@ -533,7 +553,7 @@ extern "C" int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg) {
 }
 
 extern "C" int vft_linear_variant(int variant) {
-    VFT_CHECK_ARG(variant >= -1 && variant <= 3, "vft_linear_variant: %d is not in -1..3", variant);
+    VFT_CHECK_ARG((variant >= -1 && variant <= 3) || (variant >= 11 && variant <= 13), "vft_linear_variant: %d is not in -1..3 / 11..13", variant);
     g_variant = variant;
     return 0;
 }
@@ -559,7 +579,7 @@ extern "C" int vft_linear_fwd(const void* x, const void* w, void* y, const void*
     q.x = p.x, q.w = p.w, q.y = p.y, q.bias = p.bias, q.res = p.res, q.ex = p.ex, q.ew = p.ew;
     q.M = M, q.N = N, q.K = K, q.r = p.r, q.ldx = ldx, q.ldw = ldw, q.ldy = ldy, q.ldres = ldres;
     if (g_variant >= 0 && q.r <= 16 && vft_lin8_fits(q, false)) {
-        vft_lin8_launch(q, g_variant > 0 ? g_variant : pick_tile(M, N, K, 0), false, (hipStream_t)stream);
+        launch_lin8_cfg(q, g_variant > 0 ? g_variant : pick_tile(M, N, K, 0), false, (hipStream_t)stream);
         VFT_CHECK_LAUNCH("vft_linear_fwd");
         return 0;
     }
@@ -604,7 +624,7 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
     q.M = p.M, q.N = p.N, q.K = p.K, q.r = 0, q.ldx = p.ldx, q.ldw = p.ldw, q.ldy = p.ldy, q.ldres = 0;
     q.cH = H, q.cW = W, q.cC = Cin;
     if (Cin % 64 == 0 && g_variant >= 0 && vft_lin8_fits(q, true)) {
-        vft_lin8_launch(q, g_variant > 0 ? g_variant : pick_tile(p.M, p.N, p.K, 1), true, (hipStream_t)stream);
+        launch_lin8_cfg(q, g_variant > 0 ? g_variant : pick_tile(p.M, p.N, p.K, 1), true, (hipStream_t)stream);
         VFT_CHECK_LAUNCH("vft_conv3x3_fwd");
         return 0;
     }

@@ -15,6 +15,9 @@ struct Lin8Params {
     const bf16_t* ex;    // [M][r] or null
     const bf16_t* ew;    // [N][r]
     int M, N, K, r;
+    int x_rows;          // rows of x the descriptor may address (0: M) — a split launch's first part still reads the
+                         // convolution halo rows beyond its own M
+    int m_begin;         // first row this launch covers (rows [m_begin, M)); 0 except for the tail launch of a split problem
     int64_t ldx, ldw, ldy, ldres;
     int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
     int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
@@ -27,3 +30,8 @@ bool vft_lin8_fits(const Lin8Params& p, bool conv);
 void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st);
 // tile configuration with the least last-round loss for an (M, N) problem on 256 CUs
 int vft_lin8_pick(int M, int N, int K);
+// Split launch (cfg 11 / 12 / 13 = main tile 1 / 2 / 3): the persistent workgroups take whole rounds of tiles only — rows
+// [0, M1) with M1 the largest tile-row count whose tiles fill an integer number of rounds — and the remaining rows run
+// as a second launch on the tile vft_lin8_pick chooses for them (smaller tiles: the ragged last round of a big-tile
+// launch, e.g. 828 tiles on 256 slots = 3.23 rounds, costs a whole round otherwise).  Returns M1 (0: do not split).
+int vft_lin8_split_rows(int M, int N, int main_cfg);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     // ---- persistent workgroups: virtual tile ids vt = blockIdx.x, + gridDim.x, ...; the grid is a multiple of 8, so
     //      vt & 7 labels the XCD group of every tile a workgroup takes.  id -> tile: XCD-contiguous, then bands of <= 8
     //      N-tiles walked M-major (the workgroups of one XCD share weight tiles and activation rows through its L2)
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    const int tiles_m = (p.M - p.m_begin + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
     auto decode = [&](int vt, int& m0, int& n0) {
         const int xcd = vt & 7, q = ntiles >> 3, rr = ntiles & 7;
         const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vt >> 3);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         const int nb = min(GN, tiles_n - band * GN);
         const int within = lin - band * GN * tiles_m;
         n0 = (band * GN + within % nb) * BN;
-        m0 = (within / nb) * BM;
+        m0 = p.m_begin + (within / nb) * BM;
     };
 
     // ---- LDS-DMA sources.  One instruction = 8 rows x 128 B: lane -> (row = lane>>3, slot = lane&7); the slot
@@ -452,7 +452,7 @@ void launch8(const Lin8Params& p, hipStream_t st) {
     }
     // persistent workgroups: one per resident slot (a multiple of 8, so that a workgroup stays in one XCD group), or
     // one per tile when there are fewer tiles than slots
-    const unsigned tiles = (unsigned)(((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN));
+    const unsigned tiles = (unsigned)(((p.M - p.m_begin + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN));
 #ifdef L8_NONPERSIST
     const unsigned grid = tiles;
 #else
@@ -465,7 +465,8 @@ void launch8(const Lin8Params& p, hipStream_t st) {
 
 // cfg: 1 = 256x256, 2 = 256x128, 3 = 128x128 (see linear8.h)
 static int64_t x_extent(const Lin8Params& p, bool conv) {
-    return conv ? (int64_t)p.M * p.ldx * 2 : ((int64_t)(p.M - 1) * p.ldx + p.K) * 2;
+    const int64_t rows = p.x_rows > 0 ? p.x_rows : p.M;
+    return conv ? rows * p.ldx * 2 : ((rows - 1) * p.ldx + p.K) * 2;
 }
 static int64_t w_extent(const Lin8Params& p) { return ((int64_t)(p.N - 1) * p.ldw + p.K) * 2; }
 
@@ -505,4 +506,16 @@ int vft_lin8_pick(int M, int N, int K) {
         if (t < best_t * 0.97) best_t = t, best = c;  // ties and near-ties go to the larger tile
     }
     return best;
+}
+
+int vft_lin8_split_rows(int M, int N, int main_cfg) {
+    const int bm[4] = {0, 256, 256, 128}, bn[4] = {0, 256, 128, 128}, slots[4] = {0, 256, 256, 512};
+    if (main_cfg < 1 || main_cfg > 3) return 0;
+    const long tiles_n = (N + bn[main_cfg] - 1) / bn[main_cfg];
+    const long tiles_m = (M + bm[main_cfg] - 1) / bm[main_cfg];
+    const long rounds = tiles_m * tiles_n / slots[main_cfg];
+    if (rounds < 1) return 0;
+    const long m1 = rounds * slots[main_cfg] / tiles_n;  // whole tile rows that fit `rounds` rounds
+    const long M1 = m1 * bm[main_cfg];
+    return (M1 > 0 && M1 < M) ? (int)M1 : 0;
 }
