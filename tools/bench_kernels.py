@@ -51,10 +51,18 @@ def lora_down():
     print("== vft_lora_down (t = x A^T) and vft_lora_wgrad2g at the bench shapes; GB/s of algorithmic bytes ==")
     shapes = [(98304, 640, 4), (98304, 640, 16), (98304, 1920, 16), (98304, 2560, 4), (98304, 5120, 4), (24576, 1280, 4),
               (24576, 1280, 16), (24576, 3840, 16), (24576, 5120, 4), (24576, 10240, 4), (17440, 3072, 16), (17440, 8192, 16)]
+    from vision_ft_amd import _C
     for M, K, r in shapes:
         x, A = bf(M, K), bf(r, K)
-        t = timeit(lambda: kernels.lora_down(x, A, 0.25))
-        print(f"lora_down M={M:6d} K={K:5d} r={r:2d}: {t * 1e6:7.1f} us  {2.0 * M * K / t / 1e9:7.0f} GB/s")
+        line = f"lora_down M={M:6d} K={K:5d} r={r:2d}:"
+        outs = []
+        for var in (1, 0, 2):
+            _C.lib().vft_lora_down_variant(var)
+            outs.append(kernels.lora_down(x, A, 0.25))
+            t = timeit(lambda: kernels.lora_down(x, A, 0.25))
+            line += f"  {(32, 16, 64)[var]} rows {t * 1e6:7.1f} us {2.0 * M * K / t / 1e9:6.0f} GB/s"
+        _C.lib().vft_lora_down_variant(0)
+        print(line, " equal" if torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) else " DIFFERENT", flush=True)
     for M, K, N, r in [(98304, 640, 640, 4), (98304, 640, 1920, 16), (98304, 640, 5120, 4), (98304, 2560, 640, 4),
                        (24576, 1280, 1280, 4), (24576, 1280, 3840, 16), (24576, 1280, 10240, 4), (24576, 5120, 1280, 4),
                        (17440, 3072, 3072, 16), (17440, 3072, 8192, 16), (17440, 8192, 3072, 16)]:

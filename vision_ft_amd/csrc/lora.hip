@@ -204,6 +204,63 @@ __global__ __launch_bounds__(256) void lora_rows_kernel(const bf16_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// vft_lora_down proper: t[M][r] = s · x[M][K] · w1[r][K]ᵀ with 32 token rows per workgroup.  Same MFMA arrangement as
+// phase 1 of lora_rows_kernel (16x16x32, K split over the 4 waves, partial sums reduced through LDS), but every w1
+// fragment a wave loads serves TWO 16-row groups: at rank 16 — where all 64 lanes load a w1 fragment per k-step and the
+// kernel is bound by the texture-address path, not by HBM — that is 3 loads per 2 MFMAs instead of 2 per 1.
+// ---------------------------------------------------------------------------------------------
+template <int RG>  // 16-row groups per workgroup
+__global__ __launch_bounds__(256) void lora_down32_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w1,
+                                                          bf16_t* __restrict__ t_out, int M, int K, int r, int64_t ldx,
+                                                          float s) {
+    __shared__ float red[4][16 * RG][17];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * 16 * RG;
+    {
+        const int q = lane >> 4, j = lane & 15;
+        const bool jok = j < r;
+        const bf16_t* xr[RG];
+        bool ok[RG];
+        f32x4 acc[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const int row = m0 + 16 * g + j;
+            ok[g] = row < M;
+            xr[g] = x + (int64_t)row * ldx;
+            acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const bf16_t* wr = w1 + (int64_t)j * K;
+        const int nks = (K + 31) / 32;
+#pragma unroll 4
+        for (int ks = wv; ks < nks; ks += 4) {
+            const int k = ks * 32 + 8 * q;
+            bf16x8 a[RG], b = zero8();
+#pragma unroll
+            for (int g = 0; g < RG; ++g) a[g] = zero8();
+            if (k < K) {
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    if (ok[g]) a[g] = *reinterpret_cast<const bf16x8*>(xr[g] + k);
+                if (jok) b = *reinterpret_cast<const bf16x8*>(wr + k);
+            }
+#pragma unroll
+            for (int g = 0; g < RG; ++g) acc[g] = mfma16(a[g], b, acc[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wv][16 * g + q * 4 + i][j] = acc[g][i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < RG; ++h) {
+        const int row = h * 16 + (tid >> 4), j = tid & 15;
+        const float v = red[0][row][j] + red[1][row][j] + red[2][row][j] + red[3][row][j];
+        if (j < r && m0 + row < M) t_out[(int64_t)(m0 + row) * r + j] = (bf16_t)(v * s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad stage 1: P[mb][k][j] = Σ_{m in 256-row block mb} X[m][k] · T[m][j]     (fp32, r <= 32)
 // Gᵀ tile (32 k x 32 j) per MFMA: A = Xᵀ via ds_read_b64_tr_b16 of the row-major staged X tile,
 // B = T rows (staged in LDS) in the accumulator-k order.  block = 4 waves; 64-row slabs, each wave
@@ -432,12 +489,27 @@ extern "C" int vft_lora_fwd(const void* x, void* y, const void* lora_down, const
 
 // t[M][r] = x[M][K] . lora_down[r][K]^T only (the low-rank activations; the update itself is applied by the consumer:
 // vft_geglu_lora_*, or the rank extension of vft_linear_fwd / vft_linear_nf4)
+// A/B control (vft_lora_down_variant): 0 = automatic (32 rows per workgroup; 64 at rank > 8 and M >= 65536), 1 = the 16-row
+// phase 1 of lora_rows_kernel, 2 = 64 rows, 3 = 32 rows
+static int g_lora_down_variant = 0;
+extern "C" int vft_lora_down_variant(int v) {
+    g_lora_down_variant = v;
+    return 0;
+}
+
 extern "C" int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
                              float scale, void* stream) {
     if (chk(x && lora_down && t_out, "vft_lora_down: null pointer")) return 1;
     VFT_CHECK_ARG(M > 0 && K > 0 && r > 0 && r <= 16 && K % 8 == 0 && ldx % 8 == 0, "vft_lora_down: need M,K>0, 0<r<=16, K and ldx multiples of 8");
     VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)lora_down) & 15) == 0, "vft_lora_down: operands must be 16-byte aligned");
-    launch_rows<true>(x, nullptr, lora_down, nullptr, t_out, nullptr, nullptr, 0, M, K, 0, r, ldx, 0, scale, (hipStream_t)stream);
+    if (g_lora_down_variant == 1)
+        launch_rows<true>(x, nullptr, lora_down, nullptr, t_out, nullptr, nullptr, 0, M, K, 0, r, ldx, 0, scale, (hipStream_t)stream);
+    else if (g_lora_down_variant == 2 || (g_lora_down_variant == 0 && r > 8 && M >= 65536))  // measured: 64 rows pay only there
+        hipLaunchKernelGGL(lora_down32_kernel<4>, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)lora_down, (bf16_t*)t_out, M, K, r, ldx, scale);
+    else
+        hipLaunchKernelGGL(lora_down32_kernel<2>, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)lora_down, (bf16_t*)t_out, M, K, r, ldx, scale);
     VFT_CHECK_LAUNCH("vft_lora_down");
     return 0;
 }
