@@ -335,3 +335,38 @@ def test_adapter_pack_forms_and_in_place_gradients(gpu, lora_path):
     torch.autograd.backward(outs, douts)
     for p_, r_ in zip(flat, ret):
         assert rel_err(p_.grad.float(), r_.float()) < 4e-3
+
+
+def test_sibling_projections_chain_their_data_gradients(gpu, lora_path):
+    """kernels.lora_siblings: q / k / v style LoRA projections of one input as one autograd node (data gradients chained
+    through the GEMM's residual input) against the three layers applied separately."""
+    from vision_ft_amd import kernels
+    from vision_ft_amd.modules.peft import LoRAConfig, LoRALinear
+
+    torch.manual_seed(4)
+    layers = []
+    for _ in range(3):
+        base = torch.nn.Linear(1024, 1024, bias=False, device=gpu, dtype=torch.bfloat16)
+        m = LoRALinear(LoRAConfig(rank=16, alpha=4.0), base).to(gpu)
+        with torch.no_grad():
+            m.lora_up.weight.normal_(0, 0.05)
+        layers.append(m)
+    x = torch.randn(2, 700, 1024, device=gpu).to(torch.bfloat16).requires_grad_()
+    dys = [torch.randn(2, 700, 1024, device=gpu).to(torch.bfloat16) for _ in range(3)]
+    outs = kernels.lora_siblings(x, layers)
+    if lora_path != "gemm_fused":
+        assert outs is None
+        return
+    torch.autograd.backward(outs, dys)
+    got = [x.grad.clone()] + [p.grad.clone() for m in layers for p in (m.lora_down.weight, m.lora_up.weight)]
+    x.grad = None
+    for m in layers:
+        m.lora_down.weight.grad = m.lora_up.weight.grad = None
+    ref_outs = [m(x) for m in layers]
+    torch.autograd.backward(ref_outs, dys)
+    ref = [x.grad] + [p.grad for m in layers for p in (m.lora_down.weight, m.lora_up.weight)]
+    for o, r_ in zip(outs, ref_outs):
+        assert torch.equal(o, r_)
+    assert rel_err(got[0].float(), ref[0].float()) < 6e-3
+    for g_, r_ in zip(got[1:], ref[1:]):
+        assert rel_err(g_.float(), r_.float()) < 1e-3

@@ -860,6 +860,84 @@ class _LoRALinearFused(torch.autograd.Function):
         return dx, None, None, dA, dB, None, dres, None
 
 
+class _LoRASiblings(torch.autograd.Function):
+    """Several LoRA-adapted projections of the SAME input (AuraFlow's separate q / k / v Linears and the two up projections
+    of its SwiGLU MLP, src/models/auraflow/denoiser.py:95-119,144-214): each is one fused GEMM launch forward; in the
+    backward the data gradients are CHAINED through the GEMM's residual input — dx = dy_0 W_0 + ... — instead of three
+    separate (tokens, C) tensors that autograd then adds with two more elementwise passes.
+    Arguments after x: n, s, then per projection (weight, bias, A, B, pack)."""
+
+    @staticmethod
+    def forward(ctx, x, n, s, *args):
+        x2 = _rows(x)
+        outs, saved, metas = [], [x2], []
+        with torch.cuda.device(x.device):
+            for i in range(n):
+                weight, bias, A, B, pack = args[5 * i: 5 * i + 5]
+                r = A.shape[0]
+                rp = _ext_rank(r)
+                forms = _pack_forms(pack, [(A, B)])
+                if forms is None:
+                    A_p, B_p, At, Bt = _pad_rank_rows(A.contiguous(), rp), _pad_rank_cols(B.contiguous(), rp), None, None
+                else:
+                    A_p, B_p, At, Bt = forms
+                t = lora_down(x2, A_p, s)
+                y2 = linear_fused(x2, weight, _bf16_or_none(bias), ext_x=t, ext_w=B_p)
+                outs.append(y2.view(*x.shape[:-1], weight.shape[0]))
+                saved += [t, weight, A_p, B_p, At, Bt]
+                metas.append((r, (A, B)))
+        ctx.save_for_backward(*saved)
+        ctx.n, ctx.s, ctx.metas, ctx.xshape = n, s, metas, x.shape
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        x2 = saved[0]
+        n, s = ctx.n, ctx.s
+        grads = [None] * (5 * n)
+        dx2 = None
+        with torch.cuda.device(x2.device):
+            for i in range(n):
+                t, weight, A_p, B_p, At, Bt = saved[1 + 6 * i: 7 + 6 * i]
+                r, params = ctx.metas[i]
+                if dys[i] is None:
+                    continue
+                dy2 = _bf16_rows(dys[i])
+                u = lora_down(dy2, Bt if Bt is not None else B_p.t().contiguous(), s)
+                if ctx.needs_input_grad[0]:
+                    dx2 = linear_fused(dy2, _transposed_weight(weight), None, residual=dx2, ext_x=u,
+                                       ext_w=At if At is not None else A_p.t().contiguous())
+                if ctx.needs_input_grad[3 + 5 * i + 2] or ctx.needs_input_grad[3 + 5 * i + 3]:
+                    grads[5 * i + 2], grads[5 * i + 3] = _lora_wgrad_into(x2, u, dy2, t, [params], r, A_p.shape[0], 1.0)
+        dx = dx2.view(ctx.xshape) if dx2 is not None else None
+        return (dx, None, None, *grads)
+
+
+def lora_siblings(x: torch.Tensor, layers) -> list[torch.Tensor] | None:
+    """[layer(x) for layer in layers] for LoRALinear-like modules (`.linear`, `.lora_down`, `.lora_up`, `._scale()`) that share
+    the input, with chained data gradients (see `_LoRASiblings`); None when the group is not eligible (the caller then
+    applies the layers one by one)."""
+    if not (FUSED_LORA_GEMM and x.is_cuda and len(layers) >= 2):
+        return None
+    s0 = None
+    args = []
+    for m in layers:
+        base = getattr(m, "linear", None)
+        if (base is None or not getattr(m, "enabled", False) or type(base) is not torch.nn.Linear or m.training_dropout_active()
+                or base.weight.requires_grad or not fused_lora_eligible(base.weight, m.rank)):
+            return None
+        sc = m._scale()
+        if s0 is None:
+            s0 = sc
+        elif sc != s0:
+            return None
+        args += [base.weight, base.bias, m.lora_down.weight, m.lora_up.weight, m.__dict__.get("_vft_pack")]
+    _ready(x)
+    _require_gpu(x)
+    return list(_LoRASiblings.apply(x, len(layers), float(s0), *args))
+
+
 class _LoRAQKVFused(torch.autograd.Function):
     """q, k, v of SDXL's SelfAttention (three LoRA-wrapped bias-free projections of one input,
     src/models/sdxl/denoiser.py:32-94) as ONE GEMM per direction over the concatenated frozen weights, the three

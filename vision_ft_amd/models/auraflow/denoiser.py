@@ -65,7 +65,7 @@ class AuraMLP(nn.Module):
         self.act = _act(hidden_act)
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        a, b = self.c_fc1(hidden_states), self.c_fc2(hidden_states)
+        a, b = _project_all(hidden_states, (self.c_fc1, self.c_fc2))
         gated = kernels.swiglu(a, b) if self.hidden_act == "silu" else self.act(a) * b
         return self.c_proj(gated)
 
@@ -82,6 +82,13 @@ class MultiHeadLayerNorm(nn.Module):
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         h = kernels.layer_norm(hidden_states, None, None, self.variance_epsilon)
         return (self.weight.float() * h.float()).to(hidden_states.dtype)
+
+
+def _project_all(x: torch.Tensor, layers) -> list[torch.Tensor]:
+    """[layer(x) for layer in layers]; LoRA-wrapped siblings run as one autograd node whose data gradients are chained
+    through the GEMM epilogue (kernels.lora_siblings) instead of being summed by separate elementwise passes."""
+    outs = kernels.lora_siblings(x, layers) if x.is_cuda else None
+    return outs if outs is not None else [layer(x) for layer in layers]
 
 
 def _qk_norm(norm: nn.Module, x: torch.Tensor, rope: tuple[torch.Tensor, torch.Tensor] | None) -> torch.Tensor:
@@ -126,9 +133,10 @@ class SingleAttention(nn.Module):
         b, s, _ = condition.shape
         shape = (b, s, self.n_heads, self.head_dim)
         rope = _rope_tables(rope_freqs, condition.device)
-        q = _qk_norm(self.q_norm1, self.w1q(condition).view(shape), rope)
-        k = _qk_norm(self.k_norm1, self.w1k(condition).view(shape), rope)
-        v = self.w1v(condition).view(shape)
+        pq, pk, pv = _project_all(condition, (self.w1q, self.w1k, self.w1v))
+        q = _qk_norm(self.q_norm1, pq.view(shape), rope)
+        k = _qk_norm(self.k_norm1, pk.view(shape), rope)
+        v = pv.view(shape)
         return self.w1o(_attend(q, k, v, 1 / self.head_dim**0.5))
 
 
@@ -159,11 +167,13 @@ class DoubleAttention(nn.Module):
         if rope is not None:
             rope_c = (rope[0][:sc], rope[1][:sc])
             rope_l = (rope[0][sc:], rope[1][sc:])
-        q = torch.cat([_qk_norm(self.q_norm1, self.w1q(condition).view(b, sc, H, D), rope_c),
-                       _qk_norm(self.q_norm2, self.w2q(latent).view(b, sl, H, D), rope_l)], dim=1)
-        k = torch.cat([_qk_norm(self.k_norm1, self.w1k(condition).view(b, sc, H, D), rope_c),
-                       _qk_norm(self.k_norm2, self.w2k(latent).view(b, sl, H, D), rope_l)], dim=1)
-        v = torch.cat([self.w1v(condition).view(b, sc, H, D), self.w2v(latent).view(b, sl, H, D)], dim=1)
+        q1, k1, v1 = _project_all(condition, (self.w1q, self.w1k, self.w1v))
+        q2, k2, v2 = _project_all(latent, (self.w2q, self.w2k, self.w2v))
+        q = torch.cat([_qk_norm(self.q_norm1, q1.view(b, sc, H, D), rope_c),
+                       _qk_norm(self.q_norm2, q2.view(b, sl, H, D), rope_l)], dim=1)
+        k = torch.cat([_qk_norm(self.k_norm1, k1.view(b, sc, H, D), rope_c),
+                       _qk_norm(self.k_norm2, k2.view(b, sl, H, D), rope_l)], dim=1)
+        v = torch.cat([v1.view(b, sc, H, D), v2.view(b, sl, H, D)], dim=1)
         out = _attend(q, k, v, None)
         c_out, l_out = out.split([sc, sl], dim=1)
         return self.w1o(c_out), self.w2o(l_out)

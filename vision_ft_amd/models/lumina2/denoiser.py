@@ -115,7 +115,9 @@ class FeedForward(nn.Module):
             nn.init.xavier_uniform_(lin.weight)
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        return self.w2(kernels.swiglu(self.w1(hidden_states), self.w3(hidden_states)))
+        pair = kernels.lora_siblings(hidden_states, (self.w1, self.w3)) if hidden_states.is_cuda else None  # chained data gradients
+        a, b = pair if pair is not None else (self.w1(hidden_states), self.w3(hidden_states))
+        return self.w2(kernels.swiglu(a, b))
 
 
 class TransformerBlock(nn.Module):
