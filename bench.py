@@ -123,6 +123,12 @@ def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int
     return fwd
 
 
+def _nf4_cache_on() -> bool:
+    from vision_ft_amd.modules.quant import nf4
+
+    return bool(nf4.NF4_COMPUTE_CACHE)
+
+
 def physical_cores() -> int:
     """Physical host cores available to this process (the CPU leg uses all of them)."""
     try:
@@ -391,7 +397,9 @@ def main():
                            "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5),
                            "peak_mem_gib": round(peak_timed, 1), "algorithmic_tflop_per_image": F_ALG[workload],
                            **({"buckets": bucket_note} if bucket_note else {}),
-                           **({"base_weights": "NF4 (blocksize 64, double-quantised absmax), dequantised in the GEMM kernel"}
+                           **({"base_weights": "NF4 (blocksize 64, double-quantised absmax): " + (
+                               "module state / checkpoint format; compute on a dequantised bf16 cache (VFT_NF4_CACHE=1, default)"
+                               if _nf4_cache_on() else "the only copy in HBM, dequantised inside the GEMM kernel (VFT_NF4_CACHE=0)")}
                               if workload == "lumina_qlora" else {})},
                 "roofline": roofline,
             }

@@ -1314,6 +1314,10 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
             return _LoRALinearFused.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), residual, pack)
         return _LoRALinear.apply(x, base.weight, base.bias, lora_down, lora_up, float(scale), None, residual)
     if hasattr(base, "quant_state"):  # NF4Linear: dequant-fused GEMM for the base products
+        dense = base.dense_weight() if hasattr(base, "dense_weight") else None
+        if dense is not None and FUSED_LORA_GEMM and fused_lora_eligible(dense, lora_down.shape[0]):
+            # compute cache on (modules/quant/nf4.py): the bf16 projection GEMM on the dequantised copy
+            return _LoRALinearFused.apply(x, dense, base.bias, lora_down, lora_up, float(scale), residual, pack)
         q = base.quant_state()
         r = lora_down.shape[0]
         if r in (4, 8, 16) and q.in_features % 64 == 0 and q.out_features % 64 == 0:
