@@ -161,7 +161,38 @@ def test_nf4_state_dict_layout_and_roundtrip(gpu):
         NF4Linear(128, 256).load_state_dict({"weight": torch.zeros(256, 128), "bias": torch.zeros(256)})  # not pre-quantised
 
 
-def test_qlora_tiny_lumina_step(gpu):
+@pytest.fixture(params=["bf16_compute_cache", "in_gemm_dequant"])
+def nf4_mode(request):
+    """Both compute modes of the NF4 layers: the dequantised bf16 compute copy (default) and the dequantising GEMM."""
+    from vision_ft_amd.modules.quant import nf4
+
+    old = nf4.NF4_COMPUTE_CACHE
+    nf4.NF4_COMPUTE_CACHE = request.param == "bf16_compute_cache"
+    yield request.param
+    nf4.NF4_COMPUTE_CACHE = old
+
+
+def test_nf4_compute_cache_is_bit_identical_to_the_dequantising_gemm_input(gpu):
+    """The cached copy is exactly what the dequantising kernel feeds its MFMAs (code x absmax rounded to bf16), and a layer
+    gives the same forward through either mode up to the two GEMM kernels' accumulation order."""
+    from vision_ft_amd.modules.quant import nf4
+
+    layer, _, _, _ = _make_layer(gpu, 1280, 640, True)
+    x = torch.randn(2048, 640, device=gpu).to(torch.bfloat16)
+    old = nf4.NF4_COMPUTE_CACHE
+    try:
+        nf4.NF4_COMPUTE_CACHE = True
+        assert torch.equal(layer.dense_weight(), layer.dequantize())
+        y_cache = layer(x)
+        nf4.NF4_COMPUTE_CACHE = False
+        assert layer.dense_weight() is None
+        y_gemm = layer(x)
+    finally:
+        nf4.NF4_COMPUTE_CACHE = old
+    assert rel_err(y_cache.float(), y_gemm.float()) < 3e-3
+
+
+def test_qlora_tiny_lumina_step(gpu, nf4_mode):
     """BASELINE config 4 in miniature: NF4 base (checkpoint sniffing -> NF4Linear) + bf16 LoRA on top;
     output close to the bf16 model's, LoRA gradients flow, base stays frozen and 4-bit."""
     from vision_ft_amd.models.lumina2 import Denoiser, DenoiserConfig

@@ -68,8 +68,15 @@ def lora_down():
                        (17440, 3072, 3072, 16), (17440, 3072, 8192, 16), (17440, 8192, 3072, 16)]:
         x, dy, u, tt = bf(M, K), bf(M, N), bf(M, r), bf(M, r)
         A, B = bf(r, K).requires_grad_(), bf(N, r).requires_grad_()
-        t = timeit(lambda: kernels._lora_wgrad_into(x, u, dy, tt, [(A, B)], r, r, 1.0))
-        print(f"wgrad2g  M={M:6d} K={K:5d} N={N:5d} r={r:2d}: {t * 1e6:7.1f} us  {2.0 * M * (K + N) / t / 1e9:7.0f} GB/s")
+        import ctypes
+        raw = ctypes.CDLL(_C.LIB_PATH)
+        line = f"wgrad2g  M={M:6d} K={K:5d} N={N:5d} r={r:2d}:"
+        for tgt in (1024, 2048, 4096):
+            raw.vft_lora_wgrad_target(tgt)
+            t = timeit(lambda: kernels._lora_wgrad_into(x, u, dy, tt, [(A, B)], r, r, 1.0))
+            line += f"  target {tgt}: {t * 1e6:7.1f} us {2.0 * M * (K + N) / t / 1e9:6.0f} GB/s"
+        raw.vft_lora_wgrad_target(1024)
+        print(line, flush=True)
 
 
 def attn():

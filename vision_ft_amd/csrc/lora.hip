@@ -271,9 +271,10 @@ constexpr int WG_COLS = 128, WG_LD = WG_COLS + 8;
 
 // rows of X each workgroup reduces: large enough that few partials are written, small enough that
 // (row blocks x column tiles x 2 problems) still fills 256 CUs a few times over
+static int g_wgrad_target_wgs = 1024;  // A/B (vft_lora_wgrad_target): workgroups the row blocking aims at
 __host__ inline int wgrad_rows_per_block(int M, int K, int N) {
     const int64_t ctiles = (int64_t)(K + WG_COLS - 1) / WG_COLS + (N + WG_COLS - 1) / WG_COLS;
-    int64_t rpb = ((int64_t)M * ctiles / 1024 + 63) / 64 * 64;
+    int64_t rpb = ((int64_t)M * ctiles / g_wgrad_target_wgs + 63) / 64 * 64;
     if (rpb < 256) rpb = 256;
     if (rpb > 4096) rpb = 4096;
     return (int)rpb;
@@ -522,6 +523,11 @@ extern "C" int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, 
     // phase 1 contracts over N with Bᵀ (r,N); phase 2 streams dx (M,K) with A (r,K) in JN layout
     launch_rows<false>(dy, dx, lora_up_t, lora_down, u_out, nullptr, nullptr, 0, M, N, K, r, lddy, lddx, scale, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_lora_bwd_dx");
+    return 0;
+}
+
+extern "C" int vft_lora_wgrad_target(int wgs) {
+    g_wgrad_target_wgs = wgs > 0 ? wgs : 1024;
     return 0;
 }
 
