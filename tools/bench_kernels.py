@@ -75,7 +75,7 @@ def lora_down():
             raw.vft_lora_wgrad_target(tgt)
             t = timeit(lambda: kernels._lora_wgrad_into(x, u, dy, tt, [(A, B)], r, r, 1.0))
             line += f"  target {tgt}: {t * 1e6:7.1f} us {2.0 * M * (K + N) / t / 1e9:6.0f} GB/s"
-        raw.vft_lora_wgrad_target(1024)
+        raw.vft_lora_wgrad_target(0)
         print(line, flush=True)
 
 
