@@ -97,6 +97,7 @@ int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora
  * consumer use lora_up as stored (peft/lora.py:92-104), scale = 1 gives the plain activations. */
 int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
                   float scale, void* stream);
+int vft_lora_wgrad_target(int workgroups); /* tuning / A-B: workgroups the weight-gradient row blocking aims at; 0 = automatic */
 int vft_lora_down_variant(int variant); /* tuning / A-B: 0 = automatic (32 token rows per workgroup, 64 for rank > 8 at M >= 65536), 1 = 16, 2 = 64, 3 = 32 */
 int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
                     int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream);

@@ -112,10 +112,13 @@ def attn():
 
 def norm():
     print("== norms / activations (GB/s, algorithmic bytes) ==")
-    for rows, C in [(16384, 640), (4096, 1280), (8720, 3072), (8704, 2304)]:
-        x, w, b = bf(rows, C), bf(C), bf(C)
+    for rows, C in [(98304, 640), (24576, 1280), (17440, 3072), (17408, 2304)]:  # bench shapes (SDXL B=24, AuraFlow / Lumina2 B=4)
+        x, w, b = bf(rows, C).requires_grad_(), bf(C), bf(C)
+        dy = bf(rows, C)
         tf = timeit(lambda: kernels.layer_norm(x, w, b, 1e-5))
-        print(f"layer_norm rows={rows} C={C}: {tf*1e6:7.1f} us {4*rows*C/tf/1e9:7.0f} GB/s")
+        y = kernels.layer_norm(x, w, b, 1e-5)
+        tb = timeit(lambda: torch.autograd.grad(y, x, dy, retain_graph=True))
+        print(f"layer_norm rows={rows} C={C}: fwd {tf*1e6:7.1f} us {4*rows*C/tf/1e9:6.0f} GB/s   bwd {tb*1e6:7.1f} us {6*rows*C/tb/1e9:6.0f} GB/s")
     for N, C, H, W in [(4, 320, 128, 128), (4, 640, 64, 64), (4, 1280, 32, 32), (4, 1920, 64, 64)]:
         x, w, b = bf(N, C, H, W), bf(C), bf(C)
         tf = timeit(lambda: kernels.group_norm(x, w, b, 32, 1e-5, True))

@@ -43,6 +43,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_lora_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_int64, c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_down": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_int64, c_float, c_void_p]),
     "vft_lora_down_variant": (c_int, [c_int]),
+    "vft_lora_wgrad_target": (c_int, [c_int]),
     "vft_geglu_lora_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_float, c_void_p]),
     "vft_geglu_lora_bwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "vft_lora_bwd_dx": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
