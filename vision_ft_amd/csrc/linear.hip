@@ -533,7 +533,7 @@ static void launch_lin8_cfg(Lin8Params q, int cfg, bool conv, hipStream_t st) {
             a.x_rows = b.x_rows = q.M;
             b.m_begin = M1;
             vft_lin8_launch(a, main_cfg, conv, st);
-            vft_lin8_launch(b, vft_lin8_pick(q.M - M1, q.N, q.K), conv, st);
+            vft_lin8_launch(b, vft_lin8_pick_plain(q.M - M1, q.N, q.K), conv, st);
             return;
         }
         cfg = main_cfg;

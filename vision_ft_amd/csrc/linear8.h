@@ -28,8 +28,10 @@ bool vft_lin8_fits(const Lin8Params& p, bool conv);
 
 // cfg: 1 = 256x256 tile (128 KiB LDS), 2 = 256x128 (96 KiB), 3 = 128x128 (64 KiB, two workgroups per CU).  K % 64 == 0.
 void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st);
-// tile configuration with the least last-round loss for an (M, N) problem on 256 CUs
+// tile configuration (1-3, or 11-13 = split launch) with the least modelled time for an (M, N, K) problem on 256 CUs;
+// _plain: among the one-launch configurations 1-3 only (the tail of a split launch)
 int vft_lin8_pick(int M, int N, int K);
+int vft_lin8_pick_plain(int M, int N, int K);
 // Split launch (cfg 11 / 12 / 13 = main tile 1 / 2 / 3): the persistent workgroups take whole rounds of tiles only — rows
 // [0, M1) with M1 the largest tile-row count whose tiles fill an integer number of rounds — and the remaining rows run
 // as a second launch on the tile vft_lin8_pick chooses for them (smaller tiles: the ragged last round of a big-tile

@@ -489,21 +489,40 @@ void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
     }
 }
 
-// Which tile.  Workgroups are persistent, so a launch costs ceil(tiles / resident slots) rounds of one tile each; the
-// time of a round is the tile's area over the speed a slot sustains (measured relative to the 256x256 tile on MI355X:
-// 256x128 0.86 of a CU, 128x128 two slots per CU at 0.45 each — fewer MFMAs per fragment read).  The big tile wins
-// unless its last round is mostly empty (e.g. 320 tiles on 256 CUs) or N wastes most of its last tile column.
-int vft_lin8_pick(int M, int N, int K) {
-    (void)K;
-    const double speed[4] = {0.0, 1.0, 0.86, 0.45};
+// Which tile.  Workgroups are persistent, so a launch costs ceil(tiles / resident slots) rounds of one tile each; a tile
+// costs its area x (K + K0) over the speed a slot sustains, K0 standing for the per-tile prologue / epilogue.  The four
+// constants (speed of a 256x128 slot 0.78 and of a 128x128 slot 0.35 relative to 256x256 — two of the latter share a CU;
+// K0 = 128 / 96 / 64) are fitted to the 316 measured problems of tuning_tables/gfx950_lin8_tiles.csv: choosing by this
+// model costs 0.9 % over the per-problem optimum there (the round-1 model: 8.3 %).  Split launches (whole rounds on the
+// tile + the remaining rows on the best plain tile, vft_lin8_split_rows) compete as configurations 11-13.
+static double lin8_cost(int M, int N, int K, int c) {
+    const double speed[4] = {0.0, 1.0, 0.78, 0.35}, k0[4] = {0.0, 128.0, 96.0, 64.0};
     const int bm[4] = {0, 256, 256, 128}, bn[4] = {0, 256, 128, 128}, slots[4] = {0, 256, 256, 512};
+    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
+    const long rounds = (tiles + slots[c] - 1) / slots[c];
+    return (double)rounds * bm[c] * bn[c] * (K + k0[c]) / speed[c];
+}
+static int lin8_pick_plain(int M, int N, int K, double* cost) {
     int best = 1;
-    double best_t = 1e30;
+    double best_t = 1e300;
     for (int c = 1; c <= 3; ++c) {
-        const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
-        const long rounds = (tiles + slots[c] - 1) / slots[c];
-        const double t = (double)rounds * bm[c] * bn[c] / speed[c];
+        const double t = lin8_cost(M, N, K, c);
         if (t < best_t * 0.97) best_t = t, best = c;  // ties and near-ties go to the larger tile
+    }
+    if (cost) *cost = best_t;
+    return best;
+}
+int vft_lin8_pick_plain(int M, int N, int K) { return lin8_pick_plain(M, N, K, nullptr); }
+int vft_lin8_pick(int M, int N, int K) {
+    double best_t;
+    int best = lin8_pick_plain(M, N, K, &best_t);
+    for (int c = 1; c <= 3; ++c) {
+        const int M1 = vft_lin8_split_rows(M, N, c);
+        if (M1 <= 0) continue;
+        double tail;
+        lin8_pick_plain(M - M1, N, K, &tail);
+        const double t = lin8_cost(M1, N, K, c) + tail;
+        if (t < best_t * 0.97) best_t = t, best = 10 + c;
     }
     return best;
 }
