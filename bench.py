@@ -208,14 +208,14 @@ def family_table(prof: dict, steps: int) -> dict:
 
 
 def pmc_traffic(family: str):
-    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r02_pmc_hbm_traffic.csv, falling
-    back to round 1's file: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py,
+    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r02_b_pmc_hbm_traffic.csv, falling
+    back to earlier files: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py,
     gfx950 x2 fetch correction applied) — measured at the shape named in the note, not inside this run."""
     import csv
 
-    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkdv_kernel"}.get(family)
+    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkdv3_kernel"}.get(family)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         try:
             for row in csv.DictReader(open(os.path.join(root, name))):
                 if want and row["kernel"] == want:
