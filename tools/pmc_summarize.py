@@ -21,9 +21,9 @@ ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
     # (first shape 98304 x 5120 x 640, then 24576 x 10240 x 1280: both pick the 256x256 tile); conv mode = C8<..., true>
     "lin8_kernel": None,
 }
-LIN8_SHAPES = [("lin8_kernel", "M=98304 N=5120 K=640 (+bias, rank-4 extension)", 2 * (98304 * 640 + 5120 * 640 + 98304 * 5120 + 4 * (98304 + 5120)) / 1e6),
-               ("lin8_kernel_b", "M=24576 N=10240 K=1280 (+bias, rank-4 extension)", 2 * (24576 * 1280 + 10240 * 1280 + 24576 * 10240 + 4 * (24576 + 10240)) / 1e6),
-               ("lin8_conv", "conv3x3 320->320 @128x128, B=24", (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6)]
+LIN8_SHAPES = [("lin8_kernel", "M=98304 N=5120 K=640 (+bias + rank-4 extension)", 2 * (98304 * 640 + 5120 * 640 + 98304 * 5120 + 4 * (98304 + 5120)) / 1e6),
+               ("lin8_kernel_b", "M=24576 N=10240 K=1280 (+bias + rank-4 extension)", 2 * (24576 * 1280 + 10240 * 1280 + 24576 * 10240 + 4 * (24576 + 10240)) / 1e6),
+               ("lin8_conv", "conv3x3 320->320 @128x128 B=24", (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6)]
 
 
 def per_kernel(d, counter):
