@@ -115,6 +115,18 @@ int vft_lora_wgrad2g(const void* x, const void* u, const void* dy, const void* t
                      void* const* d_up, int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes,
                      int M, int K, int N, int r, int64_t ldx, int64_t lddy, float scale, void* stream);
 
+/* Deferred reductions: vft_lora_wgrad2g_defer computes the partial sums only and records its two reductions as entries
+ * `slot`, `slot + 1` of a device table (vft_lora_wgrad_desc_bytes() bytes per entry; written by the kernel, so no
+ * host-to-device copy and capturable); vft_lora_wgrad_reduce_many(table, n, max_elements) then runs all n queued
+ * reductions in one launch (max_elements = the largest K*r or N*r among them).  The workspaces must stay untouched in
+ * between.  One training step of SDXL-LoRA: 560 + 560 launches become 560 + 1. */
+size_t vft_lora_wgrad_desc_bytes(void);
+int vft_lora_wgrad2g_defer(const void* x, const void* u, const void* dy, const void* t, void* const* d_down,
+                           void* const* d_up, int groups, int rsub, int accumulate, float* workspace,
+                           size_t ws_bytes, int M, int K, int N, int r, int64_t ldx, int64_t lddy, float scale,
+                           void* table, int slot, void* stream);
+int vft_lora_wgrad_reduce_many(const void* table, int n, int64_t max_elements, void* stream);
+
 /* All derived adapter operands of a model in one launch.  `table` (device memory) holds n descriptors of seven int64:
  * {src0, src1, src2, dst, kind | groups << 32, r | rp << 32, L}; kind 0: dst (rp,L) = the groups' lora_down (r,L) stacked
  * and zero-padded to rp rows; kind 1: its transpose (L,rp); kind 2: dst (groups*L, rp) = blockdiag of the groups'

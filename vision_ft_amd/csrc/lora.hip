@@ -305,8 +305,24 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0, 
     return __builtin_bit_cast(bf16x8, both);
 }
 
+// One deferred reduction (vft_lora_wgrad_reduce_many): written into a device table BY the partial kernel itself (one lane
+// of its first workgroup per problem), so that queueing a layer's reduction costs no host-to-device copy and is
+// capturable into a HIP graph.
+struct ReduceDesc {
+    WgradProblem p;
+    int nmb, r, accumulate;
+    float scale;
+};
+
 __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r,
-                                                                 int rows_per_block) {
+                                                                 int rows_per_block, ReduceDesc* slot, int nmb_total,
+                                                                 float scale, int accumulate) {
+    if (slot != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        ReduceDesc d;
+        d.p = blockIdx.z == 0 ? p0 : p1;
+        d.nmb = nmb_total, d.r = r, d.accumulate = accumulate, d.scale = scale;
+        slot[blockIdx.z] = d;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);                 // [64][WG_LD]
     bf16_t* Ts = reinterpret_cast<bf16_t*>(smem + 64 * WG_LD * 2);  // [64][r]
@@ -448,6 +464,32 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const PackDesc* __restri
     }
 }
 
+// every queued reduction in one launch: blockIdx.y = table entry, blockIdx.x over its K*r elements (entries with fewer
+// elements than the grid's widest leave their surplus blocks at once)
+__global__ __launch_bounds__(256) void lora_wgrad_reduce_many_kernel(const ReduceDesc* __restrict__ table) {
+    const ReduceDesc d = table[blockIdx.y];
+    const WgradProblem& p = d.p;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ne = (int64_t)p.K * d.r;
+    if (e >= ne) return;
+    const int k = (int)(e / d.r), j = (int)(e % d.r);
+    bf16_t* dst;
+    if (p.kind == 0) {
+        const int g = j / p.rsub;
+        if (g >= p.groups) return;
+        dst = p.out[g] + (int64_t)(j - g * p.rsub) * p.K + k;
+    } else {
+        const int g = k / p.ksub, jj = j - g * p.rsub;
+        if (jj < 0 || jj >= p.rsub) return;
+        dst = p.out[g] + (int64_t)(k - g * p.ksub) * p.rsub + jj;
+    }
+    float v = 0.f;
+    for (int mb = 0; mb < d.nmb; ++mb) v += p.part[(int64_t)mb * ne + e];
+    v *= d.scale;
+    if (d.accumulate) v += (float)*dst;
+    *dst = (bf16_t)v;
+}
+
 int chk(bool c, const char* msg) {
     if (!c) vft_set_error("%s", msg);
     return c ? 0 : 1;
@@ -541,7 +583,7 @@ extern "C" size_t vft_lora_wgrad_workspace(int M, int K, int N, int r) {
 
 static int wgrad_launch(const void* x, const void* u, const void* dy, const void* t, void* const* d_down, void* const* d_up,
                         int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes, int M, int K, int N, int r,
-                        int64_t ldx, int64_t lddy, float scale, void* stream, const char* name) {
+                        int64_t ldx, int64_t lddy, float scale, void* stream, const char* name, void* defer_slot = nullptr) {
     if (chk(x && u && dy && t && d_down && d_up && workspace, "vft_lora_wgrad2: null pointer")) return 1;
     VFT_CHECK_ARG(M > 0 && K > 0 && N > 0 && r > 0 && r <= 32, "%s: need M,K,N>0 and 0<r<=32", name);
     VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "%s: K, N, strides must be multiples of 8", name);
@@ -562,8 +604,9 @@ static int wgrad_launch(const void* x, const void* u, const void* dy, const void
     const size_t lds = 64 * WG_LD * 2 + 64 * (size_t)r * 2;
     const int kmax = K > N ? K : N;
     hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, 2), dim3(256), lds,
-                       (hipStream_t)stream, pa, pb, M, r, rpb);
+                       (hipStream_t)stream, pa, pb, M, r, rpb, (ReduceDesc*)defer_slot, nmb, scale, accumulate);
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(partial)");
+    if (defer_slot != nullptr) return 0;  // the reduction is queued: vft_lora_wgrad_reduce_many runs it
     const int64_t ne = (int64_t)kmax * r;
     hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 2), dim3(256), 0,
                        (hipStream_t)stream, pa, pb, nmb, r, scale, accumulate);
@@ -597,5 +640,30 @@ extern "C" int vft_lora_pack(const void* table, int n, void* stream) {
     VFT_CHECK_ARG(n > 0 && n <= 65535, "vft_lora_pack: need 0 < n <= 65535 descriptors (got %d)", n);
     hipLaunchKernelGGL(lora_pack_kernel, dim3(16, (unsigned)n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)table);
     VFT_CHECK_LAUNCH("vft_lora_pack");
+    return 0;
+}
+
+// Deferred form: only the partial sums are computed now; the two reductions (d_down, d_up) are written as entries
+// `slot`, `slot + 1` of the caller's device table (vft_lora_wgrad_desc_bytes() bytes per entry) by the kernel itself, and
+// ONE vft_lora_wgrad_reduce_many launch at the end of the backward pass runs every queued reduction — 560 + 560 launches
+// per SDXL-LoRA step become 560 + 1.  The workspace must stay untouched until then.
+extern "C" size_t vft_lora_wgrad_desc_bytes() { return sizeof(ReduceDesc); }
+
+extern "C" int vft_lora_wgrad2g_defer(const void* x, const void* u, const void* dy, const void* t, void* const* d_down,
+                                      void* const* d_up, int groups, int rsub, int accumulate, float* workspace,
+                                      size_t ws_bytes, int M, int K, int N, int r, int64_t ldx, int64_t lddy, float scale,
+                                      void* table, int slot, void* stream) {
+    if (chk(table != nullptr && slot >= 0, "vft_lora_wgrad2g_defer: null table / negative slot")) return 1;
+    return wgrad_launch(x, u, dy, t, d_down, d_up, groups, rsub, accumulate, workspace, ws_bytes, M, K, N, r, ldx, lddy, scale,
+                        stream, "vft_lora_wgrad2g_defer", (char*)table + (size_t)slot * sizeof(ReduceDesc));
+}
+
+// n entries of the table, the widest of which has max_elements = K * r output elements
+extern "C" int vft_lora_wgrad_reduce_many(const void* table, int n, int64_t max_elements, void* stream) {
+    if (chk(table != nullptr, "vft_lora_wgrad_reduce_many: null table")) return 1;
+    VFT_CHECK_ARG(n > 0 && n <= 65535 && max_elements > 0, "vft_lora_wgrad_reduce_many: need 0 < n <= 65535 entries (got %d)", n);
+    hipLaunchKernelGGL(lora_wgrad_reduce_many_kernel, dim3((unsigned)((max_elements + 255) / 256), (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, (const ReduceDesc*)table);
+    VFT_CHECK_LAUNCH("vft_lora_wgrad_reduce_many");
     return 0;
 }

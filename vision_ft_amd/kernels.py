@@ -591,13 +591,78 @@ def _grad_target(p: torch.Tensor | None):
     return g
 
 
+class _WgradQueue:
+    """Deferred LoRA weight-gradient reductions of one backward pass (per device).  Each layer's partial kernel writes its
+    two reductions into the next slots of a persistent device table and its partial sums into a slice of a persistent
+    arena; ONE `vft_lora_wgrad_reduce_many` launch — queued as an autograd engine callback, i.e. run when the backward pass
+    that produced them ends — folds them all into the gradient tensors.  Everything is launch-only (no host-to-device
+    copy), so the whole mechanism is captured into the trainer's HIP graphs like any other kernel."""
+
+    CAP = 8192  # table entries (two per adapted layer call)
+    queues: dict = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.desc_bytes = int(_C.lib().vft_lora_wgrad_desc_bytes())
+        self.table = torch.zeros(self.CAP * self.desc_bytes, dtype=torch.uint8, device=device)
+        self.arena = torch.empty(1 << 24, dtype=torch.float32, device=device)  # 64 MB to start with; grows outside capture
+        self.retired: list = []   # outgrown arenas: kept for good — reductions queued earlier in this pass, and any HIP graph
+                                  # captured before the growth, still address them (sizes double, so at most as much again)
+        self.off = 0
+        self.count = 0
+        self.max_ne = 0
+        self.callback_queued = False
+
+    @classmethod
+    def get(cls, device) -> "_WgradQueue":
+        q = cls.queues.get(device)
+        if q is None:
+            q = cls.queues[device] = cls(device)
+        return q
+
+    def take(self, nfloats: int):
+        """A slice of the arena for one layer's partial sums, or None when it cannot be had (table full, or the arena
+        would have to grow while a HIP graph is being captured): the caller then reduces immediately."""
+        nfloats = (nfloats + 63) // 64 * 64
+        if self.count + 2 > self.CAP:
+            return None
+        if self.off + nfloats > self.arena.numel():
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self.retired.append(self.arena)
+            self.arena = torch.empty(max(2 * self.arena.numel(), 2 * nfloats), dtype=torch.float32, device=self.device)
+            self.off = 0
+        ws = self.arena[self.off: self.off + nfloats]
+        self.off += nfloats
+        return ws
+
+    def flush(self) -> None:
+        self.callback_queued = False
+        if self.count:
+            with torch.cuda.device(self.device):
+                st = _C.lib().vft_lora_wgrad_reduce_many(_ptr(self.table), self.count, self.max_ne, _stream())
+            self.count, self.off, self.max_ne = 0, 0, 0
+            _C.check(st, "vft_lora_wgrad_reduce_many")
+
+
+DEFER_WGRAD_REDUCE = os.environ.get("VFT_DEFER_WGRAD", "1") != "0"  # A/B switch
+
+
+def flush_deferred_wgrads() -> None:
+    """Run the queued weight-gradient reductions now (normally the autograd engine does, at the end of backward)."""
+    for q in _WgradQueue.queues.values():
+        q.flush()
+
+
 def _lora_wgrad_into(x2, u, dy2, t, params, r: int, rp: int, s: float):
     """Weight gradients of `len(params)` adapters that share x2 — params = [(lora_down, lora_up)], 1 or 3 (fused q|k|v);
     u / t (M, rp) carry their rank-r columns side by side, dy2 their output columns side by side.
 
     When every parameter already has a gradient tensor the kernel ADDS into it (what AccumulateGrad would do with a
-    returned tensor — minus one elementwise launch per parameter) and the function returns None for each; otherwise the
-    gradients are returned: [dA_0, dB_0, dA_1, ...]."""
+    returned tensor — minus one elementwise launch per parameter) and the function returns None for each; inside a
+    backward pass the reduction itself is deferred to ONE launch at the end of the pass (`_WgradQueue`).  Otherwise the
+    gradients are returned: [dA_0, dB_0, dA_1, ...].  (With gradient tensors in place `torch.autograd.grad` on these
+    parameters would therefore see None: the trainers use `backward()`.)"""
     G = len(params)
     M, K = x2.shape
     N = dy2.shape[1]
@@ -608,9 +673,27 @@ def _lora_wgrad_into(x2, u, dy2, t, params, r: int, rp: int, s: float):
         targets = [(torch.empty((r, K), dtype=torch.bfloat16, device=x2.device),
                     torch.empty((N // G, r), dtype=torch.bfloat16, device=x2.device)) for _ in range(G)]
     nbytes = _C.lib().vft_lora_wgrad_workspace(M, K, N, rp)
-    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
     dd = (ctypes.c_void_p * 3)(*[t_[0].data_ptr() for t_ in targets])
     du = (ctypes.c_void_p * 3)(*[t_[1].data_ptr() for t_ in targets])
+    if inplace and DEFER_WGRAD_REDUCE:
+        q = _WgradQueue.get(x2.device)
+        ws = q.take(max(nbytes // 4, 1))
+        if ws is not None:
+            with _Timed("lora_wgrad2", 2.0 * M * (K + N)):
+                st = _C.lib().vft_lora_wgrad2g_defer(_ptr(x2), _ptr(u), _ptr(dy2), _ptr(t), dd, du, G, r, 1, _ptr(ws), nbytes,
+                                                     M, K, N, rp, x2.stride(0), dy2.stride(0), float(s), _ptr(q.table), q.count,
+                                                     _stream())
+            _C.check(st, "vft_lora_wgrad2g_defer")
+            q.count += 2
+            q.max_ne = max(q.max_ne, K * rp, N * rp)
+            if not q.callback_queued:
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(q.flush)
+                    q.callback_queued = True
+                except RuntimeError:  # not inside a backward pass: nothing will call back
+                    q.flush()
+            return [None] * (2 * G)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
     with _Timed("lora_wgrad2", 2.0 * M * (K + N)):
         st = _C.lib().vft_lora_wgrad2g(_ptr(x2), _ptr(u), _ptr(dy2), _ptr(t), dd, du, G, r, 1 if inplace else 0, _ptr(ws), nbytes,
                                        M, K, N, rp, x2.stride(0), dy2.stride(0), float(s), _stream())
