@@ -370,3 +370,39 @@ def test_sibling_projections_chain_their_data_gradients(gpu, lora_path):
     assert rel_err(got[0].float(), ref[0].float()) < 6e-3
     for g_, r_ in zip(got[1:], ref[1:]):
         assert rel_err(g_.float(), r_.float()) < 1e-3
+
+
+def test_grouped_kv_projection_matches_separate_layers(gpu, lora_path):
+    """kernels.lora_group (cross-attention to_k | to_v of the context as one GEMM with a rank-2r extension) against the two
+    LoRA layers applied one by one: outputs, the input gradient and the four adapter gradients."""
+    from vision_ft_amd import kernels
+    from vision_ft_amd.modules.peft import LoRAConfig, LoRALinear
+
+    torch.manual_seed(6)
+    layers = []
+    for _ in range(2):
+        base = torch.nn.Linear(2048, 640, bias=False, device=gpu, dtype=torch.bfloat16)
+        m = LoRALinear(LoRAConfig(rank=4, alpha=2.0), base).to(gpu)
+        with torch.no_grad():
+            m.lora_up.weight.normal_(0, 0.05)
+        layers.append(m)
+    ctx_ = torch.randn(3, 77, 2048, device=gpu).to(torch.bfloat16).requires_grad_()
+    dys = [torch.randn(3, 77, 640, device=gpu).to(torch.bfloat16) for _ in range(2)]
+    wkv = torch.cat([m.linear.weight.detach() for m in layers], 0).contiguous()
+    outs = kernels.lora_group(ctx_, wkv, [(m.lora_down.weight, m.lora_up.weight) for m in layers], layers[0]._scale())
+    if lora_path != "gemm_fused":
+        assert outs is None
+        return
+    torch.autograd.backward(outs, dys)
+    got = [ctx_.grad.clone()] + [p.grad.clone() for m in layers for p in (m.lora_down.weight, m.lora_up.weight)]
+    ctx_.grad = None
+    for m in layers:
+        m.lora_down.weight.grad = m.lora_up.weight.grad = None
+    ref_outs = [m(ctx_) for m in layers]
+    torch.autograd.backward(ref_outs, dys)
+    ref = [ctx_.grad] + [p.grad for m in layers for p in (m.lora_down.weight, m.lora_up.weight)]
+    for o, r_ in zip(outs, ref_outs):
+        assert rel_err(o.float(), r_.float()) < 2e-3
+    assert rel_err(got[0].float(), ref[0].float()) < 6e-3
+    for g_, r_ in zip(got[1:], ref[1:]):
+        assert rel_err(g_.float(), r_.float()) < 2e-3

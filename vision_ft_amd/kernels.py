@@ -1021,6 +1021,66 @@ def lora_siblings(x: torch.Tensor, layers) -> list[torch.Tensor] | None:
     return list(_LoRASiblings.apply(x, len(layers), float(s0), *args))
 
 
+class _LoRAGroupFused(torch.autograd.Function):
+    """G = 2 or 3 LoRA-wrapped bias-free projections of ONE input with equal shapes (SDXL CrossAttention's to_k | to_v of
+    the 77-token context, src/models/sdxl/denoiser.py:135-137) as one GEMM over the concatenated frozen weights with the
+    adapters as one rank-G·r extension (the fused q|k|v scheme without the head views).  For the context projections this
+    is about launch count and grid size: 1 848 rows fill 24-40 tiles of the 256 CUs per projection, and every adapter costs
+    four more tiny launches per step.  Returns G (…, N) views of the (rows, G·N) output."""
+
+    @staticmethod
+    def forward(ctx, x, wcat, s, pack, G, *AB):
+        x2 = _rows(x)
+        params = [(AB[2 * g], AB[2 * g + 1]) for g in range(G)]
+        r, N = params[0][0].shape[0], params[0][1].shape[0]
+        rp = _ext_rank(G * r)
+        forms = _pack_forms(pack, params)
+        if forms is None:
+            A_cat = _pad_rank_rows(torch.cat([a for a, _ in params], 0), rp)
+            B_blk = _pad_rank_cols(torch.block_diag(*[b for _, b in params]), rp)
+            At = Bt = None
+        else:
+            A_cat, B_blk, At, Bt = forms
+        with torch.cuda.device(x.device):
+            t = lora_down(x2, A_cat, s)
+            y = linear_fused(x2, wcat, None, ext_x=t, ext_w=B_blk)  # (M, G N)
+        ctx.save_for_backward(x2, wcat, t, A_cat, B_blk, At, Bt)
+        ctx.params = params
+        ctx.s, ctx.r, ctx.N, ctx.G, ctx.xshape = s, r, N, G, x.shape
+        yv = y.view(*x.shape[:-1], G, N)
+        return tuple(yv[..., g, :] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2, wcat, t, A_cat, B_blk, At, Bt = ctx.saved_tensors
+        s, r, N, G = ctx.s, ctx.r, ctx.N, ctx.G
+        M = x2.shape[0]
+        dy = torch.cat([(d if d is not None else x2.new_zeros(M, N)).reshape(M, N) for d in dys], dim=1).to(torch.bfloat16)
+        grads = [None] * (2 * G)
+        dx = None
+        with torch.cuda.device(dy.device):
+            u = lora_down(dy, Bt if Bt is not None else B_blk.t().contiguous(), s)
+            if ctx.needs_input_grad[0]:
+                dx = linear_fused(dy, _transposed_weight(wcat), None, ext_x=u,
+                                  ext_w=At if At is not None else A_cat.t().contiguous()).view(ctx.xshape)
+            if any(ctx.needs_input_grad[5:]):
+                grads = _lora_wgrad_into(x2, u, dy, t, ctx.params, r, A_cat.shape[0], 1.0)
+        return (dx, None, None, None, None, *grads)
+
+
+def lora_group(x: torch.Tensor, wcat: torch.Tensor, adapters, scale: float, pack: dict | None = None):
+    """[x W_g^T + s (x A_g^T) B_g^T for g] for G = 2 or 3 bias-free projections sharing x; wcat = cat of the frozen base
+    weights (G N, C); adapters = [(lora_down, lora_up)] * G.  None when the fused GEMM does not take the shapes."""
+    _ready(x, wcat)
+    _require_gpu(x, wcat)
+    G = len(adapters)
+    r, N = adapters[0][0].shape[0], adapters[0][1].shape[0]
+    if not (FUSED_LORA_GEMM and G in (2, 3) and fused_lora_eligible(wcat, G * r) and N % 64 == 0):
+        return None
+    flat = [t_ for pair in adapters for t_ in pair]
+    return _LoRAGroupFused.apply(x, wcat, float(scale), pack, G, *flat)
+
+
 class _LoRAQKVFused(torch.autograd.Function):
     """q, k, v of SDXL's SelfAttention (three LoRA-wrapped bias-free projections of one input,
     src/models/sdxl/denoiser.py:32-94) as ONE GEMM per direction over the concatenated frozen weights, the three

@@ -24,7 +24,7 @@ import torch.nn as nn
 from .... import kernels
 from ....modules.attention import AttentionImplementation, scaled_dot_product_attention
 from ..config import DenoiserConfig, SDXLConfig
-from ..denoiser import (CrossAttention, Denoiser, SelfAttention, TransformerBlock, _merge_heads, _proj_residual,
+from ..denoiser import (CrossAttention, Denoiser, SelfAttention, TransformerBlock, _merge_heads, _proj, _proj_residual,
                         _split_heads)
 from ..pipeline import SDXLModel
 
@@ -139,9 +139,9 @@ class SelfAttentionWithRoPE(SelfAttention, _WithRoPE):
                                        [(p.lora_down.weight, p.lora_up.weight) for p in (self.to_q, self.to_k, self.to_v)],
                                        self.to_q._scale(), self.num_heads, pack=self.__dict__.get("_vft_qkv_pack"))
         else:
-            q = _split_heads(self.to_q(hidden_states), self.num_heads, self.head_dim)
-            k = _split_heads(self.to_k(hidden_states), self.num_heads, self.head_dim)
-            v = _split_heads(self.to_v(hidden_states), self.num_heads, self.head_dim)
+            q = _split_heads(_proj(self.to_q, hidden_states), self.num_heads, self.head_dim)
+            k = _split_heads(_proj(self.to_k, hidden_states), self.num_heads, self.head_dim)
+            v = _split_heads(_proj(self.to_v, hidden_states), self.num_heads, self.head_dim)
         if self.rope_enabled:
             assert image_freqs is not None
             cos, sin = _as_table(image_freqs)
@@ -154,9 +154,10 @@ class SelfAttentionWithRoPE(SelfAttention, _WithRoPE):
 class CrossAttentionWithRoPE(CrossAttention, _WithRoPE):
     def forward(self, query: torch.Tensor, context: torch.Tensor, mask: torch.Tensor | None = None, image_freqs=None,
                 context_freqs=None, *args, residual: torch.Tensor | None = None, **kwargs) -> torch.Tensor:
-        q = _split_heads(self.to_q(query), self.num_heads, self.head_dim)
-        k = _split_heads(self.to_k(context), self.num_heads, self.head_dim)
-        v = _split_heads(self.to_v(context), self.num_heads, self.head_dim)
+        q = _split_heads(_proj(self.to_q, query), self.num_heads, self.head_dim)
+        pk, pv = self._project_kv(context)
+        k = _split_heads(pk, self.num_heads, self.head_dim)
+        v = _split_heads(pv, self.num_heads, self.head_dim)
         if self.rope_enabled:
             assert image_freqs is not None and context_freqs is not None
             q = _rotate(q, *_as_table(image_freqs))

@@ -14,6 +14,7 @@ cast points through ``accelerator.autocast()``).
 from __future__ import annotations
 
 import inspect
+import os
 from typing import Literal, NamedTuple
 
 import torch
@@ -118,11 +119,37 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, self.inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(self.inner_dim, query_dim), nn.Dropout(dropout))
 
+    def _fused_kv_weight(self) -> torch.Tensor | None:
+        """[Wk; Wv] of the frozen bases when to_k / to_v are LoRA-wrapped bf16 Linears of one rank (else None): the two
+        context projections then run as one GEMM (kernels.lora_group).  Cached; rebuilt if a base changes."""
+        ps = (self.to_k, self.to_v)
+        if not all(isinstance(p, LoRALinear) and p.enabled and not p.training_dropout_active()
+                   and type(p.linear) is nn.Linear and p.linear.bias is None and p.linear.weight.dtype == torch.bfloat16
+                   and not p.linear.weight.requires_grad and p.rank == ps[0].rank and p._scale() == ps[0]._scale() for p in ps):
+            return None
+        key = tuple((p.linear.weight.data_ptr(), p.linear.weight._version) for p in ps)
+        if getattr(self, "_wkv_key", None) != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self._wkv = torch.cat([p.linear.weight.detach() for p in ps], dim=0).contiguous()
+            self._wkv_key = key
+        return self._wkv
+
+    def _project_kv(self, context: torch.Tensor):
+        wkv = self._fused_kv_weight() if FUSE_CROSS_KV and context.is_cuda and context.dim() == 3 else None
+        if wkv is not None:
+            kv = kernels.lora_group(context, wkv, [(p.lora_down.weight, p.lora_up.weight) for p in (self.to_k, self.to_v)],
+                                    self.to_k._scale(), pack=self.__dict__.get("_vft_kv_pack"))
+            if kv is not None:
+                return kv
+        return _proj(self.to_k, context), _proj(self.to_v, context)
+
     def forward(self, query: torch.Tensor, context: torch.Tensor, mask: torch.Tensor | None = None,
                 time_embedding: torch.Tensor | None = None, *args, residual: torch.Tensor | None = None, **kwargs) -> torch.Tensor:
         q = _split_heads(_proj(self.to_q, query), self.num_heads, self.head_dim)
-        k = _split_heads(_proj(self.to_k, context), self.num_heads, self.head_dim)
-        v = _split_heads(_proj(self.to_v, context), self.num_heads, self.head_dim)
+        pk, pv = self._project_kv(context)
+        k = _split_heads(pk, self.num_heads, self.head_dim)
+        v = _split_heads(pv, self.num_heads, self.head_dim)
         attn = scaled_dot_product_attention(q, k, v, mask=mask, backend=self.attn_implementation)
         return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
@@ -131,6 +158,7 @@ class CrossAttention(nn.Module):
 # read-modify-write pass over the (M, 8C) projection.  Measured on MI355X (B=24, 1024²): +2.3 % end to end once the
 # GEGLU kernels stopped being VALU-bound on erf (before that the fusion was neutral).
 FUSE_LORA_INTO_GEGLU = True
+FUSE_CROSS_KV = os.environ.get("VFT_FUSE_KV", "1") != "0"  # A/B switch: to_k | to_v of the cross-attention context as one GEMM
 
 
 class GeGLU(nn.Module):

@@ -85,6 +85,10 @@ def build_adapter_pack(model: nn.Module):
         if callable(getattr(mod, "_fused_qkv_weight", None)) and all(isinstance(p_, LoRALinear) and hasattr(p_, "_vft_pack") for p_ in ps):
             if len({p_.rank for p_ in ps}) == 1 and len({p_.lora_up.weight.shape for p_ in ps}) == 1 and 3 * ps[0].rank <= 16:
                 mod._vft_qkv_pack = pack.add([(p_.lora_down.weight, p_.lora_up.weight) for p_ in ps], kernels._ext_rank(3 * ps[0].rank))
+        kv = [getattr(mod, n, None) for n in ("to_k", "to_v")]
+        if callable(getattr(mod, "_fused_kv_weight", None)) and all(isinstance(p_, LoRALinear) and hasattr(p_, "_vft_pack") for p_ in kv):
+            if kv[0].rank == kv[1].rank and kv[0].lora_up.weight.shape == kv[1].lora_up.weight.shape and 2 * kv[0].rank <= 16:
+                mod._vft_kv_pack = pack.add([(p_.lora_down.weight, p_.lora_up.weight) for p_ in kv], kernels._ext_rank(2 * kv[0].rank))
     if not pack.entries:
         return None
     pack.finalize()
