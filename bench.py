@@ -215,7 +215,7 @@ def pmc_traffic(family: str):
 
     want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkdv3_kernel"}.get(family)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         try:
             for row in csv.DictReader(open(os.path.join(root, name))):
                 if want and row["kernel"] == want:
