@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     const __amdgpu_buffer_rsrc_t rew = __builtin_amdgcn_make_buffer_rsrc((void*)p.ew, 0, p.N * p.r * 2, 0x00020000);
     int gx[2][DX], gw[2][DW];  // byte offsets of this lane's chunks at k = 0
     unsigned vmask[2][DX];     // CONV: which of the 9 taps fall inside the image for this lane's pixel
-    // CONV: K index = tap * Cin + c; the X halves of one K-tile are issued at different times, so each keeps its own
+    // CONV: K-tile t = (channel slice t / 9, tap t % 9); the X halves of one K-tile are issued at different times, so each keeps its own
     // incrementally advanced (tap, channel offset)
     int ctap[2] = {0, 0}, cc0[2] = {0, 0};
     auto setup = [&](int m0, int n0) {
@@ -157,10 +157,14 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
             const int off = (((tap / 3 - 1) * p.cW + (tap % 3 - 1)) * (int)p.ldx + cc0[hh]) * 2;
 #pragma unroll
             for (int q = 0; q < DX; ++q) dma16(rx, dst + q * 1024, ((vmask[hh][q] >> tap) & 1u) ? gx[hh][q] + off : OOB, 0);
-            cc0[hh] += 64;
-            if (cc0[hh] == p.cC) {
-                cc0[hh] = 0;
-                ++ctap[hh];
+            // K order of the convolution: the 9 taps of one 64-channel slice, then the next slice.  A slice's shifted
+            // pixel rows (the tile's rows and their halo, 64 channels wide) are then re-read by all nine taps while
+            // they are still in the XCD's L2 — with the channel loop inside the tap loop every tap row (dy = -1, 0, 1)
+            // came back after the workgroups of the XCD had streamed the full Cin in between, and the activation was
+            // fetched twice over (PMC: 2.0x -> measured below)
+            if (++ctap[hh] == 9) {
+                ctap[hh] = 0;
+                cc0[hh] += 64;
             }
         } else {
 #pragma unroll
@@ -169,8 +173,10 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     };
     auto stage_w = [&](int t, int buf, int hh) {
         unsigned char* dst = sm8 + buf * TILE + 2 * XH + hh * WH + wv * DW * 1024;
+        // the weight rows are [tap][Cin]: K-tile t of the order above is tap t % 9, channel slice t / 9
+        const int koff = C::CONV ? ((t % 9) * p.cC + (t / 9) * 64) * 2 : t * 128;
 #pragma unroll
-        for (int q = 0; q < DW; ++q) dma16(rw, dst + q * 1024, gw[hh][q], t * 128);
+        for (int q = 0; q < DW; ++q) dma16(rw, dst + q * 1024, gw[hh][q], koff);
     };
 
     // ---- fragment read offsets (bytes inside a half-tile): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 kk + lq;
