@@ -260,9 +260,6 @@ int vft_linear_variant(int variant);
  * cfg 1 / 2 / 3 instead of the analytic choice; cfg 0 removes the entry.  Process-wide; results do not depend on the
  * tile (same K order per output element), only the speed does. */
 int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg);
-/* Tuning / A-B of vft_conv3x3_fwd: 1 (default) = a tile's output rows are a 16x16 pixel patch (halo 1.27x), 0 = consecutive
- * pixels in row-major order (halo 2x at 128-pixel image rows).  Results are identical; only the traffic and the speed change. */
-int vft_conv_patch_order(int on);
 
 /* ---- GEMM (bf16 / NF4 weight) ----------------------------------------------------------------
  * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, weight B row-major [out,in]

@@ -229,10 +229,6 @@ def conv():
             err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
             to = timeit(lambda: kernels._conv3x3_call(x, w, b, B, H, W, Cin, Cout, "conv"), iters=10)
             line += f" | v{v} {fl/to/1e12:6.1f}" + (f" (err {err:.1e})" if err > 1e-3 else "")
-        _C.lib().vft_conv_patch_order(0)  # A/B: row-major pixel order of the output rows (automatic tile)
-        to = timeit(lambda: kernels._conv3x3_call(x, w, b, B, H, W, Cin, Cout, "conv"), iters=10)
-        _C.lib().vft_conv_patch_order(1)
-        line += f" | v0 row-major {fl/to/1e12:6.1f}"
         print(line, flush=True)
     _C.lib().vft_linear_variant(0)
 

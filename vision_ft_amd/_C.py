@@ -73,7 +73,6 @@ SIGNATURES: dict[str, tuple] = {
     "vft_linear_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_int64] * 4 + [c_void_p]),
     "vft_linear_variant": (c_int, [c_int]),
     "vft_linear_tile_hint": (c_int, [c_int] * 5),
-    "vft_conv_patch_order": (c_int, [c_int]),
     "vft_attn_variant": (c_int, [c_int]),
     "vft_gemm_nt_bf16": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_int64] * 3 + [c_void_p]),
     "vft_gemm_nf4": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_float, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),

@@ -526,8 +526,7 @@ int pick_tile(int M, int N, int K, int conv) {
 static void launch_lin8_cfg(Lin8Params q, int cfg, bool conv, hipStream_t st) {
     if (cfg >= 11) {
         const int main_cfg = cfg - 10;
-        int M1 = vft_lin8_split_rows(q.M, q.N, main_cfg);
-        if (conv) M1 &= ~255;  // both parts start on a 16x16 pixel patch (linear8.hip: patch order of the convolution's rows)
+        const int M1 = vft_lin8_split_rows(q.M, q.N, main_cfg);
         if (M1 > 0) {
             Lin8Params a = q, b = q;
             a.M = M1;
@@ -550,11 +549,6 @@ extern "C" int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg) {
         g_tile_hints.erase(tile_key(M, N, K, conv));
     else
         g_tile_hints[tile_key(M, N, K, conv)] = cfg;
-    return 0;
-}
-
-extern "C" int vft_conv_patch_order(int on) {
-    vft_lin8_conv_patch(on ? 1 : 0);
     return 0;
 }
 

@@ -20,14 +20,11 @@ struct Lin8Params {
     int m_begin;         // first row this launch covers (rows [m_begin, M)); 0 except for the tail launch of a split problem
     int64_t ldx, ldw, ldy, ldres;
     int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
-    int patch;           // CONV: 1 = output row m is pixel (m % 256) of the (m / 256)-th 16x16 pixel patch (set by the launcher
-                         // when cH % 16 == 0 and cW % 16 == 0), 0 = row m is pixel m (row-major)
     int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
 };
 
 // true when the operands fit the 32-bit offsets of the buffer descriptors (otherwise: first-generation kernel)
 bool vft_lin8_fits(const Lin8Params& p, bool conv);
-void vft_lin8_conv_patch(int on);  // A/B switch of the 16x16 patch order of the convolution's output rows
 
 // cfg: 1 = 256x256 tile (128 KiB LDS), 2 = 256x128 (96 KiB), 3 = 128x128 (64 KiB, two workgroups per CU).  K % 64 == 0.
 void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st);

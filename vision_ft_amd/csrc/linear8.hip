@@ -121,31 +121,13 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     // CONV: K-tile t = (channel slice t / 9, tap t % 9); the X halves of one K-tile are issued at different times, so each keeps its own
     // incrementally advanced (tap, channel offset)
     int ctap[2] = {0, 0}, cc0[2] = {0, 0};
-    // CONV, patch order: a tile's 256 (or 128) output rows are one 16x16 (8x16) pixel patch instead of 2 (1) image rows of up
-    // to 128 pixels, so the 3x3 halo it reads beside its own pixels is 18x18 / 16x16 = 1.27x instead of 4 rows / 2 rows = 2x.
-    // Rows are independent in x and y (one pixel = one channel row), so this is only a permutation of which pixel a tile row
-    // stands for: `prow` maps tile row -> pixel row, from a patch origin computed once per tile with scalar arithmetic.
-    int p_origin = 0, p_i0 = 0;
-    auto patch_origin = [&](int m0) {
-        if (!(C::CONV && p.patch)) return;
-        const int T = m0 >> 8, ppr = p.cW >> 4, ppi = (p.cH >> 4) * ppr;
-        const int img = T / ppi, rem = T - img * ppi, pr = rem / ppr, pc = rem - pr * ppr;
-        p_origin = img * p.cH * p.cW + (pr * p.cW + pc) * 16;
-        p_i0 = m0 & 255;
-    };
-    auto prow = [&](int m0, int row) -> int {  // pixel (= x / y row) of the tile's row `row`
-        if (!(C::CONV && p.patch)) return m0 + row;
-        const int i = p_i0 + row;
-        return p_origin + (i >> 4) * p.cW + (i & 15);
-    };
     auto setup = [&](int m0, int n0) {
-        patch_origin(m0);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
             for (int q = 0; q < DX; ++q) {
                 const int row = hh * (BM / 2) + (wv * DX + q) * 8 + drow;
-                const int pm = min(prow(m0, row), p.M - 1);
+                const int pm = min(m0 + row, p.M - 1);
                 gx[hh][q] = (int)(((int64_t)pm * p.ldx + dch * 8) * 2);
                 vmask[hh][q] = 0;
                 if (C::CONV) {
@@ -345,12 +327,6 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
 
         // ---- the next tile's first DMAs fly while this tile is written out --------------------------------------
         const int cm0 = m0, cn0 = n0;
-        const int c_origin = p_origin, c_i0 = p_i0;  // this tile's patch (setup() below moves on to the next tile's)
-        auto crow = [&](int m) -> int {              // x / y row of this tile's output row m (absolute tile-row index)
-            if (!(C::CONV && p.patch)) return m;
-            const int i = c_i0 + (m - cm0);
-            return c_origin + (i >> 4) * p.cW + (i & 15);
-        };
         const int vn = vt + gridDim.x;
         const bool more = vn < ntiles;
         if (more) {
@@ -424,7 +400,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
 #pragma unroll
                 for (int q = 0; q < EPQ; ++q) {
                     const int idx = etid + NT * q, row = idx / CH, ch = idx % CH;
-                    const int m = min(crow(mbase + row), p.M - 1), n = min(cn0 + ch * 8, p.N - 8);
+                    const int m = min(mbase + row, p.M - 1), n = min(cn0 + ch * 8, p.N - 8);
                     rv[q] = *reinterpret_cast<const bf16x8*>(p.res + (int64_t)m * p.ldres + n);
                 }
             }
@@ -456,7 +432,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rv[q][e]);
                 }
-                if (m < p.M && n < p.N) *reinterpret_cast<bf16x8*>(p.y + (int64_t)crow(m) * p.ldy + n) = v;
+                if (m < p.M && n < p.N) *reinterpret_cast<bf16x8*>(p.y + (int64_t)m * p.ldy + n) = v;
             }
             lgk0();
             bar();  // the image is re-used by the next pass
@@ -499,9 +475,6 @@ static int64_t x_extent(const Lin8Params& p, bool conv) {
 }
 static int64_t w_extent(const Lin8Params& p) { return ((int64_t)(p.N - 1) * p.ldw + p.K) * 2; }
 
-static int g_conv_patch = 1;  // A/B (vft_conv_patch_order): 0 = row-major pixel order
-void vft_lin8_conv_patch(int on) { g_conv_patch = on; }
-
 bool vft_lin8_fits(const Lin8Params& p, bool conv) {
     const int64_t lim = (1LL << 31) - 4096;
     return p.K % 64 == 0 && x_extent(p, conv) < lim && w_extent(p) < lim;
@@ -510,9 +483,6 @@ bool vft_lin8_fits(const Lin8Params& p, bool conv) {
 void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
     p.x_bytes = (int)x_extent(p, conv);
     p.w_bytes = (int)w_extent(p);
-    // patch order needs whole 16x16 patches; a split launch's two parts share the geometry (the map depends on m only)
-    const int m_full = p.x_rows > 0 ? p.x_rows : p.M;  // (a split launch's first part has its own M: decide on the whole problem)
-    p.patch = (conv && g_conv_patch && p.cH % 16 == 0 && p.cW % 16 == 0 && m_full % 256 == 0 && p.m_begin % 256 == 0) ? 1 : 0;
     if (conv) {
         if (cfg == 1) launch8<C8<256, 256, 2, true>>(p, st);
         else if (cfg == 2) launch8<C8<256, 128, 4, true>>(p, st);
