@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from vision_ft_amd import _C, kernels  # noqa: E402
 
-BATCH = {"sdxl_lora": 24, "sdxl_full": 16, "sdxl_buckets": 8, "aura_lora": 4, "lumina_lora": 4, "lumina_qlora": 4}  # bench.py defaults
+BATCH = {"sdxl_lora": 24, "sdxl_full": 16, "sdxl_buckets": 8, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4}  # bench.py defaults
 BUCKETS = [(640, 1536), (768, 1280), (768, 1408), (896, 1152), (1024, 1024), (1152, 896), (1280, 768), (1408, 768), (1536, 640)]
 
 
@@ -61,11 +61,15 @@ def main():
     ap.add_argument("--workloads", default="sdxl_lora,aura_lora,lumina_lora,sdxl_full,sdxl_buckets")
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--out", default=_C.TILE_TABLE)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch for every listed workload (default: bench.py's)")
+    ap.add_argument("--merge", action="store_true", help="keep the rows of an existing table for problems not measured now")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     shapes: set = set()
     for w in args.workloads.split(","):
+        if args.batch:
+            BATCH[w] = args.batch
         got = record(w, dev)
         print(f"{w}: {len(got)} problem sizes", flush=True)
         shapes |= got
@@ -106,6 +110,15 @@ def main():
             seen.add(r[:4])
             uniq.append(r)
     rows = uniq
+    if args.merge and os.path.exists(args.out):
+        for line in open(args.out):
+            if line[0].isdigit():
+                v = line.strip().split(",")
+                key = tuple(int(t_) for t_ in v[:4])
+                if key not in seen:
+                    seen.add(key)
+                    rows.append((*key, int(v[4]), *[float(t_) for t_ in v[5:12]]))
+        rows.sort(key=lambda r: (r[3], r[0], r[1], r[2]))
     with open(args.out, "w") as f:
         f.write("# lin8 tile per problem, measured on MI355X by tools/tune_lin8.py (TFLOP/s per tile, then the analytic choice's)\n")
         f.write("M,N,K,conv,cfg,tf_256x256,tf_256x128,tf_128x128,tf_split1,tf_split2,tf_split3,tf_analytic\n")
