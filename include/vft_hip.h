@@ -151,6 +151,16 @@ int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const voi
                     const float* mean, const float* rstd, void* dx, const void* dres, int64_t rows, int C,
                     int64_t ldx, int rows_per_batch, int kind, void* stream);
 
+/* Affine-parameter gradients of the same norms (weight / bias trainable: the full fine-tune; the ATen chain autograd
+ * runs for nn.LayerNorm's weight/bias in src/models/sdxl/denoiser.py:250-252):
+ *   dw[c] = sum_rows dy*(1+scale)*xhat, db[c] = sum_rows dy*(1+scale); either output may be NULL.
+ * scratch: vft_norm_bwd_params_scratch_floats(rows, C) floats.  out_f32: 0 = bf16 outputs, 1 = fp32.
+ * Atomic-free, fixed summation order (bit-reproducible). */
+int64_t vft_norm_bwd_params_scratch_floats(int64_t rows, int C);
+int vft_norm_bwd_params(const void* dy, const void* x, const void* scale, const float* mean, const float* rstd,
+                        void* dw, void* db, float* scratch, int64_t rows, int C, int64_t ldx,
+                        int rows_per_batch, int kind, int out_f32, void* stream);
+
 /* ---- per-head q/k norm + RoPE ---------------------------------------------------------------
  * x: (B,S,H,D) bf16 addressed by x_strides[3] = {batch, seq, head} (so views into a fused qkv
  * projection work), y/dx: (B,S,H,D) contiguous.  kind: 0 LayerNorm without affine (AuraFlow,

@@ -44,6 +44,27 @@ def test_layer_norm_affine(gpu, rows, C):
          [x, w, b], gpu, (0, 1, 2))
 
 
+def test_norm_parameter_gradients_many_slabs_and_reproducible(gpu):
+    """vft_norm_bwd_params at a row count that spans many slabs (and is no multiple of the slab), with fp32 parameters
+    too; the ordered partial sums must give bit-identical gradients run to run."""
+    from vision_ft_amd import kernels
+
+    g = _g(7)
+    rows, C = 70001, 640
+    x, w, b = _bf(g, rows, C, sc=2.0, off=0.5), _bf(g, C, sc=0.2, off=1.0), _bf(g, C, sc=0.1)
+    _run(lambda x, w, b: kernels.layer_norm(x, w, b, 1e-5), lambda x, w, b: F.layer_norm(x, (C,), w, b, 1e-5),
+         [x, w, b], gpu, (1, 2))
+    gy = _bf(g, rows, C).to(gpu)
+    outs = []
+    for dt in (torch.bfloat16, torch.bfloat16, torch.float32):
+        xw, ww, bw = x.to(gpu), w.to(gpu, dt).requires_grad_(True), b.to(gpu, dt).requires_grad_(True)
+        kernels.layer_norm(xw, ww, bw, 1e-5).backward(gy)
+        assert ww.grad.dtype == dt and bw.grad.dtype == dt
+        outs.append((ww.grad.clone(), bw.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_err(outs[2][0].float().cpu(), outs[0][0].float().cpu()) < 4e-3
+
+
 def test_layer_norm_modulate_and_rms_scale(gpu):
     from vision_ft_amd import kernels
 

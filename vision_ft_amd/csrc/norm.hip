@@ -187,6 +187,109 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(NormParams p) {
     }
 }
 
+// Affine-parameter gradients of the row norms (needed only when the norm's weight / bias train: the full fine-tune,
+// src/models/sdxl/denoiser.py:250-252 under BASELINE config 2):
+//     dw[c] = sum_rows dy * (1 + scale) * xhat        db[c] = sum_rows dy * (1 + scale)
+// Two launches, no atomics, fixed summation order (bit-reproducible): workgroup (column block of 256, row slab) keeps
+// per-thread fp32 sums of 8 columns over every 8th row of its slab, folds its 8 row lanes through LDS in lane order
+// and writes one partial row; the second kernel adds the slabs' partials in slab order.  Reads dy and x once
+// (2*rows*C*2 bytes): HBM-bound.
+struct NormParamGrad {
+    const bf16_t* dy;
+    const bf16_t* x;
+    const bf16_t* scale;
+    const float* mean;
+    const float* rstd;
+    float* part;  // [slabs][2][C]
+    void* dw;
+    void* db;
+    int64_t rows;
+    int C;
+    int64_t ldx;
+    int rpb, kind, slab_rows, slabs, out_f32;
+};
+
+__global__ __launch_bounds__(256) void norm_bwd_params_partial_kernel(NormParamGrad p) {
+    __shared__ float red[2][8][256];
+    const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + cc * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * p.slab_rows;
+    const int64_t r1 = r0 + p.slab_rows < p.rows ? r0 + p.slab_rows : p.rows;
+    float aw[8], ab[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aw[i] = 0.f, ab[i] = 0.f;
+    if (col < p.C) {
+        auto one = [&](int64_t r) {
+            float xv[8], g[8];
+            load8(p.x + r * p.ldx + col, xv);
+            load8(p.dy + r * (int64_t)p.C + col, g);
+            const float mean = p.kind == KIND_LAYER ? p.mean[r] : 0.f, rstd = p.rstd[r];
+            if (p.scale != nullptr) {
+                float t[8];
+                load8(p.scale + (r / p.rpb) * p.C + col, t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] *= (1.f + t[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                aw[i] += g[i] * ((xv[i] - mean) * rstd);
+                ab[i] += g[i];
+            }
+        };
+        int64_t r = r0 + rl;
+        for (; r + 8 < r1; r += 16) {  // two rows in flight per thread
+            one(r);
+            one(r + 8);
+        }
+        if (r < r1) one(r);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[0][rl][cc * 8 + i] = aw[i], red[1][rl][cc * 8 + i] = ab[i];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < p.C) {
+        float sw = 0.f, sb = 0.f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) sw += red[0][l][threadIdx.x], sb += red[1][l][threadIdx.x];
+        float* o = p.part + (int64_t)blockIdx.y * 2 * p.C;
+        o[c] = sw;
+        o[p.C + c] = sb;
+    }
+}
+
+// block = 64 columns x 16 slab lanes; blockIdx.y = 0 (dw) / 1 (db)
+__global__ __launch_bounds__(1024) void norm_bwd_params_reduce_kernel(NormParamGrad p) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f;
+    if (c < p.C)
+        for (int s = sl; s < p.slabs; s += 16) a += p.part[((int64_t)s * 2 + blockIdx.y) * p.C + c];
+    red[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0 && c < p.C) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][cl];
+        void* out = blockIdx.y == 0 ? p.dw : p.db;
+        if (out != nullptr) {
+            if (p.out_f32) ((float*)out)[c] = t;
+            else ((bf16_t*)out)[c] = (bf16_t)t;
+        }
+    }
+}
+
+inline void norm_param_slabs(int64_t rows, int C, int& slab_rows, int& slabs) {
+    const int colblocks = (C + 255) / 256;
+    int64_t want = 1024 / colblocks;  // ~1024 workgroups: four per CU
+    if (want < 1) want = 1;
+    int64_t sr = (rows + want - 1) / want;
+    if (sr < 64) sr = 64;
+    sr = (sr + 15) / 16 * 16;
+    slab_rows = (int)sr;
+    slabs = (int)((rows + sr - 1) / sr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-head q/k norm over head_dim D (8 elements per lane, D/8 lanes per row) + interleaved-pair
 // rotation.  x element (b,s,h,:) at x + b*sb + s*ss + h*sh ; output (B,S,H,D) contiguous.
@@ -398,6 +501,32 @@ extern "C" int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight
 #undef VFT_NORM_BWD
     }
     VFT_CHECK_LAUNCH("vft_norm_bwd_dx");
+    return 0;
+}
+
+extern "C" int64_t vft_norm_bwd_params_scratch_floats(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    int sr, sl;
+    norm_param_slabs(rows, C, sr, sl);
+    return (int64_t)sl * 2 * C;
+}
+
+extern "C" int vft_norm_bwd_params(const void* dy, const void* x, const void* scale, const float* mean, const float* rstd,
+                                   void* dw, void* db, float* scratch, int64_t rows, int C, int64_t ldx,
+                                   int rows_per_batch, int kind, int out_f32, void* stream) {
+    VFT_CHECK_ARG(dy && x && rstd && scratch && (dw || db), "vft_norm_bwd_params: null pointer");
+    VFT_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0, "vft_norm_bwd_params: unsupported C=%d", C);
+    VFT_CHECK_ARG(kind == KIND_RMS || mean != nullptr, "vft_norm_bwd_params: layer norm needs the saved mean");
+    VFT_CHECK_ARG(scale == nullptr || rows_per_batch > 0, "vft_norm_bwd_params: rows_per_batch");
+    NormParamGrad p{};
+    p.dy = (const bf16_t*)dy, p.x = (const bf16_t*)x, p.scale = (const bf16_t*)scale, p.mean = mean, p.rstd = rstd;
+    p.part = scratch, p.dw = dw, p.db = db, p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.kind = kind, p.out_f32 = out_f32;
+    norm_param_slabs(rows, C, p.slab_rows, p.slabs);
+    hipLaunchKernelGGL(norm_bwd_params_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)p.slabs), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(norm_bwd_params_reduce_kernel, dim3((unsigned)((C + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream, p);
+    VFT_CHECK_LAUNCH("vft_norm_bwd_params");
     return 0;
 }
 

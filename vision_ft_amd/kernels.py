@@ -197,8 +197,9 @@ def _bf16_or_none(t):
 
 class _RowNorm(torch.autograd.Function):
     """y = (norm(x) * w + b) * (1 + scale[b]) + shift[b] over the last dim (HIP: vft_norm_fwd / _bwd_dx).
-    Parameter / modulation gradients (only needed outside frozen-trunk LoRA runs) are reduced with
-    torch ops from the saved statistics."""
+    Weight / bias gradients (needed when the norm trains: the full fine-tune) come from vft_norm_bwd_params; the
+    per-sample modulation gradients (no BASELINE config trains the modulation's producer) are reduced with torch ops
+    from the saved statistics."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, scale, shift, kind, eps, skip=False):
@@ -242,16 +243,27 @@ class _RowNorm(torch.autograd.Function):
                                               _ptr(dres), rows, C, x2.stride(0), rpb, kind, _stream())
             _C.check(st, "vft_norm_bwd_dx")
             dx = dx2.view(xshape)
-        if any(ctx.needs_input_grad[1:5]):
+        want_w = ctx.needs_input_grad[1] and weight is not None
+        want_b = ctx.needs_input_grad[2] and bias is not None
+        if want_w or want_b:
+            # weight / bias gradients (the full fine-tune): one pass over dy and x, ordered partial sums
+            pdt = (weight if want_w else bias).dtype
+            f32 = pdt != torch.bfloat16
+            odt = torch.float32 if f32 else torch.bfloat16
+            dwk = torch.empty(C, dtype=odt, device=dy.device) if want_w else None
+            dbk = torch.empty(C, dtype=odt, device=dy.device) if want_b else None
+            scratch = torch.empty(int(_C.lib().vft_norm_bwd_params_scratch_floats(rows, C)), dtype=torch.float32, device=dy.device)
+            with torch.cuda.device(dy.device), _Timed("norm_bwd", 4.0 * rows * C):
+                st = _C.lib().vft_norm_bwd_params(_ptr(dy2), _ptr(x2), _ptr(sc), _ptr(mean), _ptr(rstd), _ptr(dwk), _ptr(dbk),
+                                                  _ptr(scratch), rows, C, x2.stride(0), rpb, kind, int(f32), _stream())
+            _C.check(st, "vft_norm_bwd_params")
+            dw = dwk.to(weight.dtype) if want_w else None
+            db = dbk.to(bias.dtype) if want_b else None
+        if any(ctx.needs_input_grad[3:5]):
             xf = x2.float()
             xh = (xf - mean[:, None]) * rstd[:, None] if kind == KIND_LAYER else xf * rstd[:, None]
             g = dy2.float()
             nb = rows // rpb
-            gm = g if sc is None else g * (1 + sc.float()).repeat_interleave(rpb, dim=0)
-            if ctx.needs_input_grad[1] and weight is not None:
-                dw = (gm * xh).sum(0).to(weight.dtype)
-            if ctx.needs_input_grad[2] and bias is not None:
-                db = gm.sum(0).to(bias.dtype)
             if ctx.needs_input_grad[3] and scale is not None:
                 base = xh if w is None else xh * w.float()
                 if b_ is not None:
