@@ -151,6 +151,17 @@ int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const voi
                     const float* mean, const float* rstd, void* dx, const void* dres, int64_t rows, int C,
                     int64_t ldx, int rows_per_batch, int kind, void* stream);
 
+/* ---- weight gradient of a trainable projection ----------------------------------------------
+ * dw[R][Cc] (+)= dy[M][R]^T . x[M][Cc]   (bf16 operands, fp32 accumulation): what autograd runs as torch.mm for the
+ * weight of F.linear when the base weights train (full fine-tune; src/models/sdxl/denoiser.py:62-64,135-137,183-204,
+ * src/modules/peft/lora.py:92-104 with the adapters merged away).  The reduction over the M tokens is split over row
+ * slices; partial tiles go to `scratch` (vft_linear_wgrad_scratch_floats(M, R, Cc) floats) and are added in slice
+ * order: no atomics, bit-reproducible.  accumulate != 0: dw += ...; out_f32: dw is fp32 instead of bf16.
+ * R % 8 == 0, Cc % 8 == 0, strides in elements (lddy, ldx % 8 == 0; lddw % 4 == 0), operands below 2 GiB. */
+int64_t vft_linear_wgrad_scratch_floats(int64_t M, int R, int Cc);
+int vft_linear_wgrad(const void* dy, const void* x, void* dw, float* scratch, int64_t M, int R, int Cc,
+                     int64_t lddy, int64_t ldx, int64_t lddw, int accumulate, int out_f32, void* stream);
+
 /* Affine-parameter gradients of the same norms (weight / bias trainable: the full fine-tune; the ATen chain autograd
  * runs for nn.LayerNorm's weight/bias in src/models/sdxl/denoiser.py:250-252):
  *   dw[c] = sum_rows dy*(1+scale)*xhat, db[c] = sum_rows dy*(1+scale); either output may be NULL.

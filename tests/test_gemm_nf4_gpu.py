@@ -345,3 +345,69 @@ def test_every_tile_variant_gives_the_same_bits(gpu):
     import torch.nn.functional as F
     refc = F.conv2d(xc.float(), wc.float(), bc.float(), padding=1)
     assert rel_err(outs[11][1].float(), refc) < 5e-3
+
+
+@pytest.mark.parametrize("M,R,Cc", [(1000, 640, 640), (16384, 1280, 1280), (4097, 320, 2560), (70, 8, 8), (5000, 264, 136),
+                                    (24576, 2560, 640)])
+def test_linear_wgrad_matches_fp32(gpu, M, R, Cc):
+    """vft_linear_wgrad (dW = dyᵀ·x, the trainable projection's weight gradient: transposed LDS reads, split reduction
+    with ordered partial sums) against the fp32 product; tolerance: bf16 rounding of the output (rel L2 < 5e-3)."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(M + R)
+    dy, x = _bf(g, M, R, sc=M**-0.5), _bf(g, M, Cc)
+    ref = dy.float().t() @ x.float()
+    assert kernels.linear_wgrad_eligible(dy.to(gpu), x.to(gpu))
+    dw = kernels.linear_wgrad(dy.to(gpu), x.to(gpu))
+    assert dw.shape == (R, Cc) and dw.dtype == torch.bfloat16
+    assert rel_err(dw.cpu(), ref) < 5e-3, rel_err(dw.cpu(), ref)
+
+
+def test_linear_wgrad_views_accumulate_fp32_and_reproducible(gpu):
+    """Strided operand views (a column block of a fused projection's gradient / input), accumulation into a view of a flat
+    gradient buffer, fp32 output, and bit-identical results run to run."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(5)
+    M, R, Cc = 9000, 640, 1280
+    dbig, xbig = _bf(g, M, 3 * R, sc=0.01).to(gpu), _bf(g, M, Cc + 64).to(gpu)
+    dy, x = dbig[:, R:2 * R], xbig[:, 64:]
+    ref = dy.float().t() @ x.float()
+    flat = torch.zeros(R * Cc + 128, dtype=torch.bfloat16, device=gpu)
+    view = flat[128:].view(R, Cc)
+    prev = _bf(g, R, Cc, sc=0.5).to(gpu)
+    view.copy_(prev)
+    kernels.linear_wgrad(dy, x, out=view, accumulate=True)
+    assert rel_err(view.float().cpu(), (ref + prev.float()).cpu()) < 5e-3
+    assert torch.equal(flat[:128], torch.zeros(128, dtype=torch.bfloat16, device=gpu))
+    o32 = torch.empty(R, Cc, dtype=torch.float32, device=gpu)
+    kernels.linear_wgrad(dy, x, out=o32)
+    assert rel_err(o32.cpu(), ref.cpu()) < 2e-5, rel_err(o32.cpu(), ref.cpu())
+    a, b = kernels.linear_wgrad(dy, x), kernels.linear_wgrad(dy, x)
+    assert torch.equal(a, b)
+
+
+def test_linear_trained_gradients_and_in_place_accumulation(gpu):
+    """A trainable nn.Linear through kernels.linear_trained: outputs and input / weight / bias gradients against fp32
+    autograd, and the weight gradient accumulated straight into an existing `.grad` (the trainer's flat-buffer view)."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(11)
+    B, S, Cin, Cout = 2, 2500, 640, 1280
+    x, w, b = _bf(g, B, S, Cin), _bf(g, Cout, Cin, sc=Cin**-0.5), _bf(g, Cout, sc=0.1)
+    gy = _bf(g, B, S, Cout, sc=0.02)
+    xr, wr, br = (t.float().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.linear(xr, wr, br).backward(gy.float())
+    xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    assert kernels.trained_linear_eligible(xg, wg)
+    y = kernels.linear_trained(xg, wg, bg)
+    assert rel_err(y.float().cpu(), torch.nn.functional.linear(x.float(), w.float(), b.float())) < 5e-3
+    y.backward(gy.to(gpu))
+    for got, ref in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        assert rel_err(got.float().cpu(), ref) < 6e-3, rel_err(got.float().cpu(), ref)
+    # second pass: .grad exists now -> accumulated in place by the kernel (autograd gets None for the weight)
+    before, ptr = wg.grad.clone(), wg.grad.data_ptr()
+    kernels.linear_trained(xg, wg, bg).backward(gy.to(gpu))
+    assert wg.grad.data_ptr() == ptr
+    assert rel_err(wg.grad.float().cpu(), 2 * wr.grad) < 8e-3
+    assert not torch.equal(before, wg.grad)

@@ -1594,6 +1594,65 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     return _Linear.apply(x, weight, bias, residual)
 
 
+# Trainable projections (full fine-tune).  Forward and data gradient stay on the table-tuned library GEMMs (see
+# `linear_eligible`); the WEIGHT gradient of the small-output projections — the attention's square q / k / v / out
+# matrices, 280 of the SDXL step's 323 Linears — runs on vft_linear_wgrad, which beats the tuned library there (measured on
+# MI355X, B = 16: 1280 x 1280 over 16 384 tokens 87 vs 124 us, 640 x 640 over 65 536 tokens 103 vs 177 us) and accumulates
+# straight into the parameter's gradient (no AccumulateGrad pass).  Large outputs (the FeedForward matrices) are faster on
+# the library and stay there.
+TRAINED_LINEAR_WGRAD = os.environ.get("VFT_TRAINED_WGRAD", "1") != "0"  # A/B switch
+
+
+def trained_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    if not (TRAINED_LINEAR_WGRAD and weight.requires_grad and x.is_cuda and x.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and weight.dim() == 2 and torch.is_grad_enabled()):
+        return False
+    R, Cc = weight.shape
+    M = x.numel() // x.shape[-1]
+    tiles = ((R + 255) // 256) * ((Cc + 255) // 256)
+    return M >= 4096 and R % 8 == 0 and Cc % 8 == 0 and tiles <= 30 and (M + 130) * max(R, Cc) * 2 < 2**31
+
+
+class _LinearTrained(torch.autograd.Function):
+    """F.linear of a trainable weight (src/models/sdxl/denoiser.py:62-64,135-137): library GEMMs forward and for the data
+    gradient, vft_linear_wgrad for the weight gradient, accumulated into `weight.grad` when the trainer has pointed it into
+    its flat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        wparam, bparam = ctx.params
+        dy2, x2 = _bf16_rows(dy), _bf16_rows(x)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            g = _grad_target(wparam)
+            if linear_wgrad_eligible(dy2, x2):
+                with torch.cuda.device(dy.device):
+                    if g is not None:
+                        linear_wgrad(dy2, x2, out=g, accumulate=True)
+                    else:
+                        dw = linear_wgrad(dy2, x2)
+            else:
+                dw = dy2.t() @ x2
+        if bparam is not None and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear_trained(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    _ready(x, weight)
+    _require_gpu(x, weight, bias)
+    return _LinearTrained.apply(x, weight, bias)
+
+
 # =============================================================================================
 # 3x3 convolution (implicit GEMM on the fused-linear kernel), channels-last
 # =============================================================================================
@@ -1708,6 +1767,40 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.float().sum(0).to(dy.dtype)
         return dx, dw, db, (dy if ctx.has_add and ctx.needs_input_grad[3] else None)
+
+
+def linear_wgrad_eligible(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
+    """2-D bf16 operands with unit column stride whose extents the kernel's 32-bit offsets cover."""
+    if dy2.dim() != 2 or x2.dim() != 2 or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
+        return False
+    M, R = dy2.shape
+    Cc = x2.shape[1]
+    if dy2.stride(1) != 1 or x2.stride(1) != 1 or R % 8 or Cc % 8 or dy2.stride(0) % 8 or x2.stride(0) % 8:
+        return False
+    if (dy2.data_ptr() | x2.data_ptr()) & 15:
+        return False
+    return (M + 130) * dy2.stride(0) * 2 < 2**31 and (M + 130) * x2.stride(0) * 2 < 2**31
+
+
+def linear_wgrad(dy2: torch.Tensor, x2: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """dW[R, Cc] (+)= dy2[M, R]ᵀ · x2[M, Cc] on the hand-written split-reduction kernel (vft_linear_wgrad): the weight
+    gradient of a trainable projection.  `out` (bf16 or fp32, row-major, may be a view into a flat gradient buffer)
+    receives the result, added to its previous content when `accumulate`."""
+    _require_gpu(dy2, x2)
+    M, R = dy2.shape
+    Cc = x2.shape[1]
+    if out is None:
+        out = torch.empty((R, Cc), dtype=torch.bfloat16, device=dy2.device)
+        accumulate = False
+    if out.dim() != 2 or out.shape != (R, Cc) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("linear_wgrad: `out` must be a row-major (R, Cc) bf16 / fp32 matrix")
+    lib = _C.lib()
+    scratch = torch.empty(int(lib.vft_linear_wgrad_scratch_floats(M, R, Cc)), dtype=torch.float32, device=dy2.device)
+    with torch.cuda.device(dy2.device), _Timed("linear_wgrad", 2.0 * M * R * Cc):
+        st = lib.vft_linear_wgrad(_ptr(dy2), _ptr(x2), _ptr(out), _ptr(scratch), M, R, Cc, dy2.stride(0), x2.stride(0),
+                                  out.stride(0), int(bool(accumulate)), int(out.dtype == torch.float32), _stream())
+    _C.check(st, "vft_linear_wgrad")
+    return out
 
 
 def _conv1x1_wt(weight: torch.Tensor) -> torch.Tensor:
