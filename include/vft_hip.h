@@ -162,6 +162,14 @@ int64_t vft_linear_wgrad_scratch_floats(int64_t M, int R, int Cc);
 int vft_linear_wgrad(const void* dy, const void* x, void* dw, float* scratch, int64_t M, int R, int Cc,
                      int64_t lddy, int64_t ldx, int64_t lddw, int accumulate, int out_f32, void* stream);
 
+/* Weight gradient of the 3x3 / stride 1 / padding 1 convolution (NHWC; src/models/sdxl/denoiser.py:511-551 with trainable
+ * weights): dw[Cout][tap][Cin] (+)= sum over pixels of dy[pixel][Cout] * x[pixel + tap offset][Cin], the im2col implicit
+ * (shifted row reads, image borders masked).  Same kernel, scratch and ordering guarantees as vft_linear_wgrad.
+ * W % 8 == 0, Cin % 8 == 0, Cout % 8 == 0. */
+int64_t vft_conv3x3_wgrad_scratch_floats(int64_t pixels, int Cout, int Cin);
+int vft_conv3x3_wgrad(const void* dy, const void* x, void* dw, float* scratch, int B, int H, int W, int Cin, int Cout,
+                      int accumulate, int out_f32, void* stream);
+
 /* Affine-parameter gradients of the same norms (weight / bias trainable: the full fine-tune; the ATen chain autograd
  * runs for nn.LayerNorm's weight/bias in src/models/sdxl/denoiser.py:250-252):
  *   dw[c] = sum_rows dy*(1+scale)*xhat, db[c] = sum_rows dy*(1+scale); either output may be NULL.

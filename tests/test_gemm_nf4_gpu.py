@@ -411,3 +411,33 @@ def test_linear_trained_gradients_and_in_place_accumulation(gpu):
     assert wg.grad.data_ptr() == ptr
     assert rel_err(wg.grad.float().cpu(), 2 * wr.grad) < 8e-3
     assert not torch.equal(before, wg.grad)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 64, 64), (1, 640, 320, 41, 104), (3, 192, 1280, 48, 32),
+                                            (5, 64, 72, 30, 40), (1, 1280, 640, 64, 64)])
+def test_conv3x3_weight_gradient_kernel(gpu, B, Cin, Cout, H, W):
+    """vft_conv3x3_wgrad (implicit im2col: shifted pixel rows, image borders masked, images back to back in one
+    reduction) against fp32 autograd of F.conv2d; also through kernels.conv3x3's backward with the gradient
+    accumulated into an existing channels-last `.grad`."""
+    import torch.nn.functional as F
+
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(B * 1000 + Cin)
+    x, gy = _bf(g, B, Cin, H, W), _bf(g, B, Cout, H, W, sc=(H * W) ** -0.5)
+    w = _bf(g, Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5)
+    wr = w.float().requires_grad_(True)
+    F.conv2d(x.float(), wr, None, padding=1).backward(gy.float())
+    assert kernels.conv3x3_wgrad_eligible(B, H, W, Cin, Cout)
+    xg = x.to(gpu).contiguous(memory_format=torch.channels_last)
+    gg = gy.to(gpu).contiguous(memory_format=torch.channels_last)
+    dw = kernels.conv3x3_wgrad(gg, xg).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    assert rel_err(dw.float().cpu(), wr.grad) < 6e-3, rel_err(dw.float().cpu(), wr.grad)
+    # through autograd, twice: the second pass accumulates in place into the channels-last gradient
+    wg = w.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    kernels.conv3x3(xg, wg, None).backward(gg)
+    assert rel_err(wg.grad.float().cpu(), wr.grad) < 6e-3
+    wg.grad = wg.grad.contiguous(memory_format=torch.channels_last)
+    ptr = wg.grad.data_ptr()
+    kernels.conv3x3(xg, wg, None).backward(gg)
+    assert wg.grad.data_ptr() == ptr and rel_err(wg.grad.float().cpu(), 2 * wr.grad) < 8e-3

@@ -96,7 +96,23 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     // ---- LDS-DMA sources.  One instruction = 4 rows x 256 B: lane -> (row = lane >> 4, slot = lane & 15); the slot holds
     //      source chunk slot ^ ((row & 7) << 1)
     int ga[2][DX], gb[2][DW];  // byte offsets of this lane's chunks at the slice's first reduction tile
+    // CONV: the 8 pixel rows a wave stages per reduction tile (rows 8 wv .. 8 wv + 7 of the tile) lie in ONE image row
+    // (W % 8 == 0), so the image coordinates of the wave's first pixel are wave-uniform and advance on the scalar unit
+    // (64 pixels per reduction tile); a lane adds its 0..7.  Taps are per half: (tdy, tdx) of the half's tap.
+    int s_oh = 0, s_ow = 0, tdy[2] = {0, 0}, tdx[2] = {0, 0};
+    const int q64 = CONV ? 64 / p.cW : 0, r64 = CONV ? 64 % p.cW : 0;
+    const int lrow = lane >> 4;
     auto setup = [&]() {
+        if (CONV) {
+            const int m0 = kt0 * 64 + 8 * wv, pix = m0 % (p.cH * p.cW);
+            s_oh = __builtin_amdgcn_readfirstlane(pix / p.cW);
+            s_ow = __builtin_amdgcn_readfirstlane(pix % p.cW);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int tap = (h0 + hh) / hpt;
+                tdy[hh] = tap / 3 - 1, tdx[hh] = tap % 3 - 1;
+            }
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -123,8 +139,23 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     auto stage_b = [&](int t, int buf, int hh) {
         unsigned char* dst = smw + buf * TILE + 2 * HALF + hh * HALF + wv * DW * 1024;
         const int adv = t * stepb;
+        if (CONV) {
+            // the two halves of a reduction tile are always staged half 0 first, tiles in order: advance with half 0
+            if (hh == 0 && t != 0) {
+                s_ow += r64, s_oh += q64;
+                if (s_ow >= p.cW) s_ow -= p.cW, s_oh += 1;
+                while (s_oh >= p.cH) s_oh -= p.cH;
+            }
+            const bool rowok = (unsigned)(s_oh + tdy[hh]) < (unsigned)p.cH;
 #pragma unroll
-        for (int q = 0; q < DW; ++q) dma16(rb, dst + q * 1024, (int)((unsigned)gb[hh][q] + (unsigned)adv));
+            for (int q = 0; q < DW; ++q) {
+                const bool ok = rowok && (unsigned)(s_ow + 4 * q + lrow + tdx[hh]) < (unsigned)p.cW;
+                dma16(rb, dst + q * 1024, ok ? (int)((unsigned)gb[hh][q] + (unsigned)adv) : OOB);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < DW; ++q) dma16(rb, dst + q * 1024, (int)((unsigned)gb[hh][q] + (unsigned)adv));
+        }
     };
 
     // ---- transposed fragment reads: lane group g = lane >> 4 takes rows 4g + q (+16 for the second read), q = (lane & 15) >> 2,
@@ -362,7 +393,8 @@ int run_wgrad(const void* dy, const void* x, void* dw, float* scratch, int64_t M
     VFT_CHECK_ARG((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) & 15) == 0, "%s: misaligned pointer", name);
     const int64_t xcols = conv ? cC : Cc;
     VFT_CHECK_ARG(ldx >= xcols, "%s: strides", name);
-    VFT_CHECK_ARG(!conv || (Cc == 9 * cC && cH > 0 && cW > 0 && M % ((int64_t)cH * cW) == 0), "%s: convolution geometry", name);
+    VFT_CHECK_ARG(!conv || (Cc == 9 * cC && cH > 0 && cW > 0 && cW % 8 == 0 && M % ((int64_t)cH * cW) == 0),
+                  "%s: convolution geometry (W %% 8 == 0)", name);
     const int64_t ab = ((M - 1) * lddy + R) * 2, bb = ((M - 1) * ldx + xcols) * 2;
     // the per-lane offsets (row advance included) are 32-bit; 64 rows of slack for the last, partial reduction tile
     VFT_CHECK_ARG(ab + 130 * lddy < (int64_t)1 << 31 && bb + 130 * ldx < (int64_t)1 << 31, "%s: operand beyond 2 GiB", name);
@@ -393,5 +425,20 @@ extern "C" int vft_linear_wgrad(const void* dy, const void* x, void* dw, float* 
     const int st = run_wgrad(dy, x, dw, scratch, M, R, Cc, lddy, ldx, lddw, accumulate, out_f32, 0, 0, 0, stream, "vft_linear_wgrad");
     if (st != 0) return st;
     VFT_CHECK_LAUNCH("vft_linear_wgrad");
+    return 0;
+}
+
+extern "C" int64_t vft_conv3x3_wgrad_scratch_floats(int64_t pixels, int Cout, int Cin) {
+    if (pixels <= 0 || Cout <= 0 || Cin <= 0) return 0;
+    return (int64_t)pick_slices(pixels, Cout, 9 * ((Cin + 127) / 128)) * Cout * 9 * Cin;
+}
+
+extern "C" int vft_conv3x3_wgrad(const void* dy, const void* x, void* dw, float* scratch, int B, int H, int W, int Cin, int Cout,
+                                 int accumulate, int out_f32, void* stream) {
+    const int64_t M = (int64_t)B * H * W;
+    const int st = run_wgrad(dy, x, dw, scratch, M, Cout, 9 * Cin, Cout, Cin, 9 * (int64_t)Cin, accumulate, out_f32, H, W, Cin, stream,
+                             "vft_conv3x3_wgrad");
+    if (st != 0) return st;
+    VFT_CHECK_LAUNCH("vft_conv3x3_wgrad");
     return 0;
 }

@@ -1701,6 +1701,7 @@ class _Conv3x3(torch.autograd.Function):
         y = _conv3x3_call(x, w, b_, B, H, W, Cin, Cout, "conv3x3_fwd")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.wparam = weight
         return y
 
     @staticmethod
@@ -1713,11 +1714,63 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _conv3x3_call(dy, _dgrad_weight(weight), None, B, H, W, Cout, Cin, "conv3x3_dgrad")
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if need_w or need_b:  # weight gradient (full fine-tune only): MIOpen
+        if need_w and conv3x3_wgrad_eligible(B, H, W, Cin, Cout):
+            # weight gradient (full fine-tune only) on vft_conv3x3_wgrad, accumulated straight into the parameter's
+            # channels-last gradient (the trainer's flat buffer) when there is one
+            g2 = _conv_grad_target(ctx.wparam)
+            with torch.cuda.device(dy.device):
+                if g2 is not None:
+                    conv3x3_wgrad(dy, x, out=g2, accumulate=True)
+                else:
+                    dw = conv3x3_wgrad(dy, x).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).to(weight.dtype)
+            if need_b:
+                db = dy.permute(0, 2, 3, 1).reshape(-1, Cout).sum(0)
+        elif need_w or need_b:  # geometries the kernel does not take: MIOpen
             _, dw, db = torch.ops.aten.convolution_backward(
                 dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                 [False, bool(need_w), bool(need_b)])
         return dx, dw, db
+
+
+CONV_WGRAD_KERNEL = os.environ.get("VFT_CONV_WGRAD", "1") != "0"  # A/B switch
+
+
+def conv3x3_wgrad_eligible(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    return (CONV_WGRAD_KERNEL and W % 8 == 0 and Cin % 8 == 0 and Cout % 8 == 0 and B * H * W >= 4096
+            and (B * H * W + 130) * max(Cin, Cout) * 2 < 2**31)
+
+
+def _conv_grad_target(weight: torch.Tensor | None):
+    """[Cout, 9*Cin] view ([tap][Cin] rows) of a convolution weight's existing channels-last bf16 gradient, or None."""
+    g = getattr(weight, "grad", None) if weight is not None else None
+    if g is None or g.dtype != torch.bfloat16 or not g.is_cuda or g.dim() != 4 or g.shape != weight.shape:
+        return None
+    g2 = g.permute(0, 2, 3, 1)
+    if not g2.is_contiguous() or g.data_ptr() % 16:
+        return None
+    return g2.reshape(g.shape[0], -1)
+
+
+def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """dW[Cout, 9*Cin] (rows = [tap][Cin], the channels-last weight layout) of a 3x3 / stride 1 / padding 1 convolution from
+    the channels-last output gradient dy (B,Cout,H,W) and input x (B,Cin,H,W): implicit im2col inside vft_conv3x3_wgrad."""
+    _require_gpu(dy, x)
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    x = x.contiguous(memory_format=torch.channels_last)
+    if out is None:
+        out = torch.empty((Cout, 9 * Cin), dtype=torch.bfloat16, device=dy.device)
+        accumulate = False
+    if out.shape != (Cout, 9 * Cin) or not out.is_contiguous() or out.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("conv3x3_wgrad: `out` must be a contiguous (Cout, 9*Cin) bf16 / fp32 matrix")
+    lib = _C.lib()
+    scratch = torch.empty(int(lib.vft_conv3x3_wgrad_scratch_floats(B * H * W, Cout, Cin)), dtype=torch.float32, device=dy.device)
+    with _Timed("conv3x3_wgrad", 2.0 * B * H * W * Cout * 9 * Cin):
+        st = lib.vft_conv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(out), _ptr(scratch), B, H, W, Cin, Cout, int(bool(accumulate)),
+                                   int(out.dtype == torch.float32), _stream())
+    _C.check(st, "vft_conv3x3_wgrad")
+    return out
 
 
 def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
