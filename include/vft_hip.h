@@ -180,6 +180,12 @@ int vft_norm_bwd_params(const void* dy, const void* x, const void* scale, const 
                         void* dw, void* db, float* scratch, int64_t rows, int C, int64_t ldx,
                         int rows_per_batch, int kind, int out_f32, void* stream);
 
+/* out[c] (+)= sum over rows of dy[row][c]: the bias gradient of a trainable nn.Linear / nn.Conv2d (what autograd runs as
+ * aten::sum; src/models/sdxl/denoiser.py:74,167,183-204,511-551 with trainable biases).  scratch:
+ * vft_norm_bwd_params_scratch_floats(rows, C) floats.  Ordered partial sums, bit-reproducible. */
+int vft_colsum(const void* dy, void* out, float* scratch, int64_t rows, int C, int64_t ld, int accumulate, int out_f32,
+               void* stream);
+
 /* ---- per-head q/k norm + RoPE ---------------------------------------------------------------
  * x: (B,S,H,D) bf16 addressed by x_strides[3] = {batch, seq, head} (so views into a fused qkv
  * projection work), y/dx: (B,S,H,D) contiguous.  kind: 0 LayerNorm without affine (AuraFlow,

@@ -411,6 +411,7 @@ def test_linear_trained_gradients_and_in_place_accumulation(gpu):
     assert wg.grad.data_ptr() == ptr
     assert rel_err(wg.grad.float().cpu(), 2 * wr.grad) < 8e-3
     assert not torch.equal(before, wg.grad)
+    assert rel_err(bg.grad.float().cpu(), 2 * br.grad) < 8e-3  # vft_colsum accumulated into the existing bias gradient
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 64, 64), (1, 640, 320, 41, 104), (3, 192, 1280, 48, 32),
@@ -435,9 +436,13 @@ def test_conv3x3_weight_gradient_kernel(gpu, B, Cin, Cout, H, W):
     assert rel_err(dw.float().cpu(), wr.grad) < 6e-3, rel_err(dw.float().cpu(), wr.grad)
     # through autograd, twice: the second pass accumulates in place into the channels-last gradient
     wg = w.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    kernels.conv3x3(xg, wg, None).backward(gg)
+    bg = torch.zeros(Cout, dtype=torch.bfloat16, device=gpu, requires_grad=True)
+    kernels.conv3x3(xg, wg, bg).backward(gg)
     assert rel_err(wg.grad.float().cpu(), wr.grad) < 6e-3
+    bref = gy.float().sum((0, 2, 3))
+    assert rel_err(bg.grad.float().cpu(), bref) < 6e-3
     wg.grad = wg.grad.contiguous(memory_format=torch.channels_last)
     ptr = wg.grad.data_ptr()
-    kernels.conv3x3(xg, wg, None).backward(gg)
+    kernels.conv3x3(xg, wg, bg).backward(gg)
     assert wg.grad.data_ptr() == ptr and rel_err(wg.grad.float().cpu(), 2 * wr.grad) < 8e-3
+    assert rel_err(bg.grad.float().cpu(), 2 * bref) < 8e-3

@@ -205,8 +205,8 @@ struct NormParamGrad {
     void* db;
     int64_t rows;
     int C;
-    int64_t ldx;
-    int rpb, kind, slab_rows, slabs, out_f32;
+    int64_t ldx, lddy;
+    int rpb, kind, slab_rows, slabs, out_f32, accumulate;
 };
 
 __global__ __launch_bounds__(256) void norm_bwd_params_partial_kernel(NormParamGrad p) {
@@ -221,8 +221,13 @@ __global__ __launch_bounds__(256) void norm_bwd_params_partial_kernel(NormParamG
     if (col < p.C) {
         auto one = [&](int64_t r) {
             float xv[8], g[8];
+            load8(p.dy + r * p.lddy + col, g);
+            if (p.x == nullptr) {  // column sums only (vft_colsum)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ab[i] += g[i];
+                return;
+            }
             load8(p.x + r * p.ldx + col, xv);
-            load8(p.dy + r * (int64_t)p.C + col, g);
             const float mean = p.kind == KIND_LAYER ? p.mean[r] : 0.f, rstd = p.rstd[r];
             if (p.scale != nullptr) {
                 float t[8];
@@ -273,8 +278,8 @@ __global__ __launch_bounds__(1024) void norm_bwd_params_reduce_kernel(NormParamG
         for (int l = 0; l < 16; ++l) t += red[l][cl];
         void* out = blockIdx.y == 0 ? p.dw : p.db;
         if (out != nullptr) {
-            if (p.out_f32) ((float*)out)[c] = t;
-            else ((bf16_t*)out)[c] = (bf16_t)t;
+            if (p.out_f32) ((float*)out)[c] = t + (p.accumulate ? ((float*)out)[c] : 0.f);
+            else ((bf16_t*)out)[c] = (bf16_t)(t + (p.accumulate ? (float)((bf16_t*)out)[c] : 0.f));
         }
     }
 }
@@ -521,12 +526,30 @@ extern "C" int vft_norm_bwd_params(const void* dy, const void* x, const void* sc
     NormParamGrad p{};
     p.dy = (const bf16_t*)dy, p.x = (const bf16_t*)x, p.scale = (const bf16_t*)scale, p.mean = mean, p.rstd = rstd;
     p.part = scratch, p.dw = dw, p.db = db, p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch > 0 ? rows_per_batch : 1;
-    p.kind = kind, p.out_f32 = out_f32;
+    p.kind = kind, p.out_f32 = out_f32, p.lddy = C;
     norm_param_slabs(rows, C, p.slab_rows, p.slabs);
     hipLaunchKernelGGL(norm_bwd_params_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)p.slabs), dim3(256), 0,
                        (hipStream_t)stream, p);
     hipLaunchKernelGGL(norm_bwd_params_reduce_kernel, dim3((unsigned)((C + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream, p);
     VFT_CHECK_LAUNCH("vft_norm_bwd_params");
+    return 0;
+}
+
+// Column sums of a [rows][C] bf16 matrix (row stride ld): the bias gradient of a trainable projection / convolution
+// (sum over tokens or pixels of dy), same two ordered passes as the norm parameter gradients.
+extern "C" int vft_colsum(const void* dy, void* out, float* scratch, int64_t rows, int C, int64_t ld, int accumulate,
+                          int out_f32, void* stream) {
+    VFT_CHECK_ARG(dy && out && scratch, "vft_colsum: null pointer");
+    VFT_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && ld >= C, "vft_colsum: unsupported C=%d", C);
+    VFT_CHECK_ARG(((uintptr_t)dy & 15) == 0, "vft_colsum: misaligned pointer");
+    NormParamGrad p{};
+    p.dy = (const bf16_t*)dy, p.part = scratch, p.db = out, p.rows = rows, p.C = C, p.lddy = ld, p.rpb = 1;
+    p.out_f32 = out_f32, p.accumulate = accumulate;
+    norm_param_slabs(rows, C, p.slab_rows, p.slabs);
+    hipLaunchKernelGGL(norm_bwd_params_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)p.slabs), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(norm_bwd_params_reduce_kernel, dim3((unsigned)((C + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream, p);
+    VFT_CHECK_LAUNCH("vft_colsum");
     return 0;
 }
 

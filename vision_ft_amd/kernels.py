@@ -1609,8 +1609,14 @@ def trained_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
         return False
     R, Cc = weight.shape
     M = x.numel() // x.shape[-1]
+    return M >= 4096 and R % 8 == 0 and Cc % 8 == 0
+
+
+def _wgrad_on_kernel(M: int, R: int, Cc: int) -> bool:
+    """Small outputs (at most 30 tiles of 256 x 256: the attention projections) — there the split-reduction kernel beats the
+    tuned library; the FeedForward matrices are faster on the library."""
     tiles = ((R + 255) // 256) * ((Cc + 255) // 256)
-    return M >= 4096 and R % 8 == 0 and Cc % 8 == 0 and tiles <= 30 and (M + 130) * max(R, Cc) * 2 < 2**31
+    return tiles <= 30 and (M + 130) * max(R, Cc) * 2 < 2**31
 
 
 class _LinearTrained(torch.autograd.Function):
@@ -1634,7 +1640,7 @@ class _LinearTrained(torch.autograd.Function):
             dx = (dy2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             g = _grad_target(wparam)
-            if linear_wgrad_eligible(dy2, x2):
+            if _wgrad_on_kernel(dy2.shape[0], weight.shape[0], weight.shape[1]) and linear_wgrad_eligible(dy2, x2):
                 with torch.cuda.device(dy.device):
                     if g is not None:
                         linear_wgrad(dy2, x2, out=g, accumulate=True)
@@ -1643,7 +1649,7 @@ class _LinearTrained(torch.autograd.Function):
             else:
                 dw = dy2.t() @ x2
         if bparam is not None and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            db = colsum(dy2, bparam)
         return dx, dw, db
 
 
@@ -1701,7 +1707,7 @@ class _Conv3x3(torch.autograd.Function):
         y = _conv3x3_call(x, w, b_, B, H, W, Cin, Cout, "conv3x3_fwd")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.wparam = weight
+        ctx.wparam, ctx.bparam = weight, bias
         return y
 
     @staticmethod
@@ -1724,7 +1730,7 @@ class _Conv3x3(torch.autograd.Function):
                 else:
                     dw = conv3x3_wgrad(dy, x).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).to(weight.dtype)
             if need_b:
-                db = dy.permute(0, 2, 3, 1).reshape(-1, Cout).sum(0)
+                db = colsum(dy.permute(0, 2, 3, 1).reshape(-1, Cout), ctx.bparam)
         elif need_w or need_b:  # geometries the kernel does not take: MIOpen
             _, dw, db = torch.ops.aten.convolution_backward(
                 dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
@@ -1820,6 +1826,28 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.float().sum(0).to(dy.dtype)
         return dx, dw, db, (dy if ctx.has_add and ctx.needs_input_grad[3] else None)
+
+
+def colsum(dy2: torch.Tensor, param: torch.Tensor | None = None) -> torch.Tensor | None:
+    """Column sums of a (rows, C) bf16 matrix on vft_colsum — the bias gradient of a trainable projection / convolution.
+    With `param` (the bias parameter) whose `.grad` is an existing dense bf16 tensor the sums are ACCUMULATED into it and
+    None is returned (nothing left for autograd to add); otherwise the sums are returned in the parameter's dtype."""
+    rows, C = dy2.shape
+    if (dy2.dtype != torch.bfloat16 or dy2.stride(1) != 1 or C % 8 or dy2.stride(0) % 8 or dy2.data_ptr() % 16 or rows < 1024):
+        out = dy2.sum(0)
+        return out if param is None else out.to(param.dtype)
+    g = _grad_target(param)
+    odt = torch.float32 if (param is not None and param.dtype == torch.float32) else torch.bfloat16
+    out = g if g is not None else torch.empty(C, dtype=odt, device=dy2.device)
+    lib = _C.lib()
+    scratch = torch.empty(int(lib.vft_norm_bwd_params_scratch_floats(rows, C)), dtype=torch.float32, device=dy2.device)
+    with torch.cuda.device(dy2.device), _Timed("colsum", 2.0 * rows * C):
+        st = lib.vft_colsum(_ptr(dy2), _ptr(out), _ptr(scratch), rows, C, dy2.stride(0), int(g is not None),
+                            int(out.dtype == torch.float32), _stream())
+    _C.check(st, "vft_colsum")
+    if g is not None:
+        return None
+    return out if param is None else out.to(param.dtype)
 
 
 def linear_wgrad_eligible(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
