@@ -182,10 +182,11 @@ FAMILIES = {
     "linear_gemm": (("linear_fwd",), "lin8_kernel (vft_linear_fwd: base GEMM + bias + LoRA rank extension + skip, forward and data gradient)", "mfma"),
     "attention_bwd": (("attn_bwd",), "attn_bwd_dkdv_kernel + attn_bwd_dq_kernel", "mfma"),
     "attention_fwd": (("attn_fwd",), "attn_fwd_kernel", "mfma"),
-    "conv3x3": (("conv3x3",), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
+    "conv3x3": (("conv3x3_fwd", "conv3x3_dgrad"), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
+    "weight_grad": (("linear_wgrad", "conv3x3_wgrad"), "wg8_kernel (vft_linear_wgrad / vft_conv3x3_wgrad: weight gradients of trainable projections and 3x3 convolutions)", "mfma"),
     "gemm_nf4": (("gemm_nf4",), "linear_kernel NF4 modes (vft_linear_nf4)", "mfma"),
     "lora_rank": (("lora_",), "lora_rows_kernel / lora_wgrad kernels", "hbm"),
-    "norms_activations": (("norm_", "groupnorm_", "geglu_", "swiglu_", "gate_residual", "qk_norm_rope"), "norm / GroupNorm / GEGLU / SwiGLU kernels", "hbm"),
+    "norms_activations": (("norm_", "groupnorm_", "geglu_", "swiglu_", "gate_residual", "qk_norm_rope", "colsum"), "norm / GroupNorm / GEGLU / SwiGLU / column-sum kernels", "hbm"),
 }
 
 
@@ -215,7 +216,7 @@ def pmc_traffic(family: str):
 
     want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkdv3_kernel"}.get(family)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         try:
             for row in csv.DictReader(open(os.path.join(root, name))):
                 if want and row["kernel"] == want:

@@ -52,6 +52,19 @@ def main():
     ka = prof.key_averages()
     print(ka.table(sort_by="self_cuda_time_total", row_limit=args.top, max_name_column_width=60))
     print("=" * 100)
+    print("by input shape:")
+    kshape = sorted(prof.key_averages(group_by_input_shape=True),
+                    key=lambda e: -getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)))
+    n = 0
+    for e in kshape:
+        t = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))
+        if not e.key.startswith("aten::") or t <= 0 or e.key in ("aten::mm", "aten::addmm"):
+            continue
+        print(f"{e.key:28s} n={e.count:5d} dev={t / 1000:8.2f} ms  {str(e.input_shapes)[:150]}")
+        n += 1
+        if n >= 40:
+            break
+    print("=" * 100)
     ks = prof.key_averages(group_by_stack_n=6)
     rows = sorted(ks, key=lambda e: -getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)))
     shown = 0

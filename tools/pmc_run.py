@@ -55,3 +55,18 @@ for _ in range(3):
     kernels.conv3x3(xc, wc, bc).backward(gyc)
 torch.cuda.synchronize()
 print("conv3x3 algorithmic bytes (x + y + w) =", 2 * Bc * Hc * Hc * (Ci + Co) + 2 * 9 * Ci * Co)
+
+# weight-gradient kernel (wg8) of the full fine-tune, B = 16: the 1280 x 1280 attention projection over the 32x32-latent
+# tokens, and the 3x3 convolution 640 -> 640 at 64x64 (implicit im2col)
+Mw, Rw, Cw = 16384, 1280, 1280
+dyw, xw = bf(Mw, Rw) * 0.01, bf(Mw, Cw)
+for _ in range(3):
+    kernels.linear_wgrad(dyw, xw)
+Bq, Cq, Hq = 16, 640, 64
+xq = bf(Bq, Cq, Hq, Hq).contiguous(memory_format=torch.channels_last)
+gq = (bf(Bq, Cq, Hq, Hq) * 0.01).contiguous(memory_format=torch.channels_last)
+for _ in range(3):
+    kernels.conv3x3_wgrad(gq, xq)
+torch.cuda.synchronize()
+print("wg8 linear algorithmic bytes (dy + x + dW) =", 2 * (Mw * Rw + Mw * Cw + Rw * Cw),
+      " wg8 conv (dy + x + dW) =", 2 * (2 * Bq * Hq * Hq * Cq + 9 * Cq * Cq))

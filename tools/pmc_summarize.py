@@ -20,6 +20,13 @@ ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
     # round 2: the second-generation GEMM.  Its two plain instantiations are told apart by launch order in tools/pmc_run.py
     # (first shape 98304 x 5120 x 640, then 24576 x 10240 x 1280: both pick the 256x256 tile); conv mode = C8<..., true>
     "lin8_kernel": None,
+    # weight-gradient kernel: linear mode = wg8_kernel<false> (ILb0E), convolution mode = <true>; their fp32 partial tiles
+    # (write, then read by wg8_reduce_kernel) are on top of the algorithmic operand bytes
+    "wg8_kernelILb0E": 2 * (16384 * 1280 * 2 + 1280 * 1280) / 1e6,
+    "wg8_kernelILb1E": 2 * (2 * 16 * 64 * 64 * 640 + 9 * 640 * 640) / 1e6,
+    "wg8_kernel<false>": 2 * (16384 * 1280 * 2 + 1280 * 1280) / 1e6,
+    "wg8_kernel<true>": 2 * (2 * 16 * 64 * 64 * 640 + 9 * 640 * 640) / 1e6,
+    "wg8_reduce_kernel": None,
 }
 LIN8_SHAPES = [("lin8_kernel", "M=98304 N=5120 K=640 (+bias + rank-4 extension)", 2 * (98304 * 640 + 5120 * 640 + 98304 * 5120 + 4 * (98304 + 5120)) / 1e6),
                ("lin8_kernel_b", "M=24576 N=10240 K=1280 (+bias + rank-4 extension)", 2 * (24576 * 1280 + 10240 * 1280 + 24576 * 10240 + 4 * (24576 + 10240)) / 1e6),

@@ -40,6 +40,8 @@ def main():
             return "gemm(hipblaslt)"
         if "igemm" in n or "Im2d2Col" in n or "Col2Im" in n or "SubTensorOp" in n or "transpose" in n.lower() or "ck::" in n or "naive_conv" in n:
             return "conv(miopen/ck)"
+        if "wg8_" in n:
+            return "weight grad(ours, wg8)"
         if "lin8_kernel" in n:
             return "conv3x3(ours, lin8)" if "ELb1EE" in n or ", true>" in n else "linear gemm(ours, lin8)"
         if "linear_kernel" in n:
@@ -62,7 +64,7 @@ def main():
     for k, v in cat.items():
         agg[cls(k)] += v
     for k, v in agg.most_common():
-        print(f"  {k:22s} {v/1e6:8.2f} ms {100*v/tot:5.1f}%")
+        print(f"  {k:24s} {v/1e6:8.2f} ms {100*v/tot:5.1f}%")
     print("name,calls,total_ms,avg_us")
     for k, v in cat.most_common(top):
         print(f"{k},{calls[k]},{v/1e6:.3f},{v/calls[k]/1e3:.1f}")

@@ -80,9 +80,14 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     const int tiles_r = (p.R + BM - 1) / BM, tiles_c = (nhalves + 1) / 2, ntiles = tiles_r * tiles_c;
     const int nitems = ntiles * p.slices, nkt_all = (p.M + 63) / 64;
     int r0, h0, kt0, nkt, slice;
+    // id -> item: XCD-contiguous (workgroup ids go round-robin over the 8 XCDs and the grid is a multiple of 8 or a single
+    // round, so vt & 7 labels the XCD): one XCD takes whole slices, whose tiles share their dy / x column blocks through
+    // that XCD's L2 (measured: FETCH_SIZE of the 1280 x 1280 x 16384 problem 420 MB with round-robin items)
     auto decode = [&](int vt) {
-        slice = vt / ntiles;
-        const int tile = vt - slice * ntiles;
+        const int xcd = vt & 7, q = nitems >> 3, rr = nitems & 7;
+        const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vt >> 3);
+        slice = lin / ntiles;
+        const int tile = lin - slice * ntiles;
         r0 = (tile / tiles_c) * BM;
         h0 = (tile % tiles_c) * 2;
         kt0 = (int)((int64_t)slice * nkt_all / p.slices);
