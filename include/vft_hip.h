@@ -146,10 +146,12 @@ int vft_lora_pack(const void* table, int n, void* stream);
 int vft_norm_fwd(const void* x, void* y, const void* weight, const void* bias, const void* scale,
                  const void* shift, float* mean, float* rstd, int64_t rows, int C, int64_t ldx,
                  int rows_per_batch, int kind, float eps, void* stream);
-/* dres (optional, [rows][C]): gradient arriving through the residual path around the norm; dx = norm_bwd + dres */
+/* dres, dres2 (optional, [rows][C]): gradients arriving through the residual path(s) around the norm — the block input
+ * feeds the norm and one or two skip connections (auraflow/denoiser.py:392-422: both gated adds of a block take the
+ * block input); dx = norm_bwd + dres + dres2 */
 int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const void* scale,
-                    const float* mean, const float* rstd, void* dx, const void* dres, int64_t rows, int C,
-                    int64_t ldx, int rows_per_batch, int kind, void* stream);
+                    const float* mean, const float* rstd, void* dx, const void* dres, const void* dres2, int64_t rows,
+                    int C, int64_t ldx, int rows_per_batch, int kind, void* stream);
 
 /* ---- weight gradient of a trainable projection ----------------------------------------------
  * dw[R][Cc] (+)= dy[M][R]^T . x[M][Cc]   (bf16 operands, fp32 accumulation): what autograd runs as torch.mm for the
@@ -198,7 +200,8 @@ int vft_qk_norm_rope_fwd(const void* x, void* y, const void* weight, const float
                          int64_t cs_batch_stride, int kind, float eps, void* stream);
 int vft_qk_norm_rope_bwd(const void* dy, const void* x, const void* weight, const float* cos,
                          const float* sin, const float* mean, const float* rstd, void* dx, int B, int S,
-                         int H, int D, const int64_t* x_strides, int64_t cs_batch_stride, int kind,
+                         int H, int D, const int64_t* x_strides, const int64_t* dy_strides /* {batch, seq, head} in
+                         elements, multiples of 8; NULL = contiguous (B,S,H,D) */, int64_t cs_batch_stride, int kind,
                          void* stream);
 
 /* ---- GroupNorm (+SiLU), NCHW ---------------------------------------------------------------

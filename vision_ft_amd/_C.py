@@ -55,7 +55,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_lora_wgrad_reduce_many": (c_int, [c_void_p, c_int, c_int64, c_void_p]),
     "vft_lora_pack": (c_int, [c_void_p, c_int, c_void_p]),
     "vft_norm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
-    "vft_norm_bwd_dx": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
+    "vft_norm_bwd_dx": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "vft_linear_wgrad_scratch_floats": (c_int64, [c_int64, c_int, c_int]),
     "vft_linear_wgrad": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "vft_conv3x3_wgrad_scratch_floats": (c_int64, [c_int64, c_int, c_int]),
@@ -64,7 +64,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_colsum": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "vft_norm_bwd_params": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "vft_qk_norm_rope_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [_I64P, c_int64, c_int, c_float, c_void_p]),
-    "vft_qk_norm_rope_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [_I64P, c_int64, c_int, c_void_p]),
+    "vft_qk_norm_rope_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [_I64P, _I64P, c_int64, c_int, c_void_p]),
     "vft_groupnorm_scratch_floats": (c_int64, [c_int] * 6),
     "vft_groupnorm_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "vft_groupnorm_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_float, c_int, c_void_p]),

@@ -30,6 +30,7 @@ struct NormParams {
     const bf16_t* dy;     // backward
     bf16_t* dx;           // backward
     const bf16_t* dres;   // backward, optional [rows][C]: gradient arriving through the residual path, added to dx
+    const bf16_t* dres2;  // backward, optional: a second residual-path gradient (the input feeds two skip connections)
     int64_t rows;
     int C;
     int64_t ldx;
@@ -182,6 +183,12 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(NormParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += t[i];
             }
+            if (p.dres2 != nullptr) {
+                float t[8];
+                load8(p.dres2 + row * (int64_t)C + col, t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += t[i];
+            }
             store8(dxr + col, o);
         }
     }
@@ -312,6 +319,7 @@ struct QkParams {
     bf16_t* dx;        // contiguous (B,S,H,D)
     int B, S, H, D;
     int64_t sb, ss, sh;
+    int64_t dsb, dss, dsh;  // backward: strides of dy (elements)
     int64_t cs_bstride;
     int kind;
     float eps;
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkParams p) {
     } else {
         // dy -> inverse rotation -> norm backward
         float d[8];
-        load8(p.dy + rr * D + gl * 8, d);
+        load8(p.dy + b * p.dsb + s * p.dss + h * p.dsh + gl * 8, d);
         float g[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -486,15 +494,15 @@ extern "C" int vft_norm_fwd(const void* x, void* y, const void* weight, const vo
 }
 
 extern "C" int vft_norm_bwd_dx(const void* dy, const void* x, const void* weight, const void* scale, const float* mean,
-                               const float* rstd, void* dx, const void* dres, int64_t rows, int C, int64_t ldx,
-                               int rows_per_batch, int kind, void* stream) {
+                               const float* rstd, void* dx, const void* dres, const void* dres2, int64_t rows, int C,
+                               int64_t ldx, int rows_per_batch, int kind, void* stream) {
     VFT_CHECK_ARG(dy && x && dx && rstd, "vft_norm_bwd_dx: null pointer");
     VFT_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * MAXCH, "vft_norm_bwd_dx: unsupported C=%d", C);
     VFT_CHECK_ARG(kind == KIND_RMS || mean != nullptr, "vft_norm_bwd_dx: layer norm needs the saved mean");
     NormParams p{};
     p.x = (const bf16_t*)x, p.dy = (const bf16_t*)dy, p.dx = (bf16_t*)dx, p.w = (const bf16_t*)weight;
-    p.dres = (const bf16_t*)dres;
-    VFT_CHECK_ARG(dres == nullptr || ((uintptr_t)dres & 15) == 0, "vft_norm_bwd_dx: misaligned residual gradient");
+    p.dres = (const bf16_t*)dres, p.dres2 = (const bf16_t*)dres2;
+    VFT_CHECK_ARG((((uintptr_t)dres | (uintptr_t)dres2) & 15) == 0, "vft_norm_bwd_dx: misaligned residual gradient");
     p.scale = (const bf16_t*)scale, p.mean = const_cast<float*>(mean), p.rstd = const_cast<float*>(rstd);
     p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch, p.kind = kind;
     const dim3 grid((unsigned)((rows + 3) / 4));
@@ -578,9 +586,12 @@ extern "C" int vft_qk_norm_rope_fwd(const void* x, void* y, const void* weight, 
 
 extern "C" int vft_qk_norm_rope_bwd(const void* dy, const void* x, const void* weight, const float* cos,
                                     const float* sin, const float* mean, const float* rstd, void* dx, int B, int S,
-                                    int H, int D, const int64_t* x_strides, int64_t cs_batch_stride, int kind,
-                                    void* stream) {
+                                    int H, int D, const int64_t* x_strides, const int64_t* dy_strides,
+                                    int64_t cs_batch_stride, int kind, void* stream) {
     VFT_CHECK_ARG(dy && x && dx, "vft_qk_norm_rope_bwd: null pointer");
+    VFT_CHECK_ARG(dy_strides == nullptr || (dy_strides[0] % 8 == 0 && dy_strides[1] % 8 == 0 && dy_strides[2] % 8 == 0 &&
+                                            ((uintptr_t)dy & 15) == 0),
+                  "vft_qk_norm_rope_bwd: dy strides must be multiples of 8 elements");
     if (qk_args("vft_qk_norm_rope_bwd", B, S, H, D, x_strides, kind)) return 1;
     VFT_CHECK_ARG(kind == KIND_NONE || rstd != nullptr, "vft_qk_norm_rope_bwd: saved statistics missing");
     QkParams p{};
@@ -588,6 +599,8 @@ extern "C" int vft_qk_norm_rope_bwd(const void* dy, const void* x, const void* w
     p.cos = cos, p.sin = sin, p.mean = const_cast<float*>(mean), p.rstd = const_cast<float*>(rstd);
     p.B = B, p.S = S, p.H = H, p.D = D;
     p.sb = x_strides[0], p.ss = x_strides[1], p.sh = x_strides[2], p.cs_bstride = cs_batch_stride, p.kind = kind;
+    p.dsb = dy_strides ? dy_strides[0] : (int64_t)S * H * D, p.dss = dy_strides ? dy_strides[1] : (int64_t)H * D;
+    p.dsh = dy_strides ? dy_strides[2] : D;
     launch_qk<true>(p, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_qk_norm_rope_bwd");
     return 0;

@@ -217,21 +217,30 @@ class _RowNorm(torch.autograd.Function):
         _C.check(st, "vft_norm_fwd")
         ctx.save_for_backward(x2, w, b_, sc, mean, rstd)
         ctx.meta = (kind, rpb, x.shape, weight, bias, scale, shift)
-        ctx.skip = bool(skip)
+        ctx.skip = int(skip)
+        if ctx.skip == 2:  # the block input feeds the norm AND two skip connections (AuraFlow's blocks)
+            return y.view(x.shape), x, x.view_as(x)
         if skip:  # (normed, x): the second output carries the residual path, so that its gradient meets the
             return y.view(x.shape), x  # norm's own in ONE kernel instead of an autograd accumulation add
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy, dskip=None):
+    def backward(ctx, dy, dskip=None, dskip2=None):
         x2, w, b_, sc, mean, rstd = ctx.saved_tensors
         kind, rpb, xshape, weight, bias, scale, shift = ctx.meta
         rows, C = x2.shape
-        dres = None
-        if dskip is not None:
-            dres = dskip.reshape(rows, C)
-            if dres.dtype != torch.bfloat16 or not dres.is_contiguous():
-                dres = dres.to(torch.bfloat16).contiguous()
+
+        def _res(d):
+            if d is None:
+                return None
+            d = d.reshape(rows, C)
+            if d.dtype != torch.bfloat16 or not d.is_contiguous():
+                d = d.to(torch.bfloat16).contiguous()
+            return d
+
+        dres, dres2 = _res(dskip), _res(dskip2)
+        if dres is None:
+            dres, dres2 = dres2, None
         dy2 = dy.reshape(rows, C)
         if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
             dy2 = dy2.to(torch.bfloat16).contiguous()
@@ -240,7 +249,7 @@ class _RowNorm(torch.autograd.Function):
             dx2 = torch.empty((rows, C), dtype=torch.bfloat16, device=dy.device)
             with torch.cuda.device(dy.device), _Timed("norm_bwd", 6.0 * rows * C):
                 st = _C.lib().vft_norm_bwd_dx(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(sc), _ptr(mean), _ptr(rstd), _ptr(dx2),
-                                              _ptr(dres), rows, C, x2.stride(0), rpb, kind, _stream())
+                                              _ptr(dres), _ptr(dres2), rows, C, x2.stride(0), rpb, kind, _stream())
             _C.check(st, "vft_norm_bwd_dx")
             dx = dx2.view(xshape)
         want_w = ctx.needs_input_grad[1] and weight is not None
@@ -296,9 +305,11 @@ def rms_norm(x: torch.Tensor, weight, eps: float) -> torch.Tensor:
     return _norm(x, weight, None, None, None, KIND_RMS, eps)
 
 
-def layer_norm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """AdaLN: LN(x) (no affine, fp32 stats) * (1 + scale[:,None]) + shift[:,None]   (x: B,S,C; shift/scale: B,C)."""
-    return _norm(x, None, None, scale, shift, KIND_LAYER, eps)
+def layer_norm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-5, skips: int = 0):
+    """AdaLN: LN(x) (no affine, fp32 stats) * (1 + scale[:,None]) + shift[:,None]   (x: B,S,C; shift/scale: B,C).
+    skips = 1 / 2: also returns x once / twice — use those outputs as the residual inputs of the block's gated adds, so
+    that their gradients are added inside the norm-backward kernel instead of by autograd accumulation passes."""
+    return _norm(x, None, None, scale, shift, KIND_LAYER, eps, skip=skips)
 
 
 def rms_norm_scale(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor | None, eps: float) -> torch.Tensor:
@@ -499,11 +510,14 @@ class _QkNormRope(torch.autograd.Function):
         x, w, cos, sin, mean, rstd = ctx.saved_tensors
         kind, cs_b, weight = ctx.meta
         B, S, H, D = x.shape
-        d2 = dy.contiguous()
+        d2 = dy  # strided views (dq / dk slices of the attention backward's fused dq|dk|dv buffer) are read in place
+        if dy.stride(3) != 1 or any(st % 8 for st in dy.stride()[:3]) or dy.data_ptr() % 16 or dy.dtype != torch.bfloat16:
+            d2 = dy.to(torch.bfloat16).contiguous()
         dx = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=x.device)
         with torch.cuda.device(x.device), _Timed("qk_norm_rope_bwd", 6.0 * x.numel()):
             st = _C.lib().vft_qk_norm_rope_bwd(_ptr(d2), _ptr(x), _ptr(w), _ptr(cos), _ptr(sin), _ptr(mean), _ptr(rstd),
-                                               _ptr(dx), B, S, H, D, _C.i64x3(x.stride()[:3]), cs_b, kind, _stream())
+                                               _ptr(dx), B, S, H, D, _C.i64x3(x.stride()[:3]), _C.i64x3(d2.stride()[:3]),
+                                               cs_b, kind, _stream())
         _C.check(st, "vft_qk_norm_rope_bwd")
         dw = None
         if ctx.needs_input_grad[1] and weight is not None:

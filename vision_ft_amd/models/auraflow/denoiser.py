@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -179,6 +181,18 @@ class DoubleAttention(nn.Module):
         return self.w1o(c_out), self.w2o(l_out)
 
 
+BLOCK_SKIPS = os.environ.get("VFT_BLOCK_SKIPS", "1") != "0"  # A/B switch
+
+
+def _norm_with_skips(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float):
+    """(AdaLN(x), x, x): a block's input feeds its first norm and both of its gated adds (`x + g1*att`, `x + g2*mlp`,
+    src/models/auraflow/denoiser.py:392-422 of the reference); taking the two residual inputs from the norm's extra outputs
+    lets the three gradients of x meet inside the norm-backward kernel instead of in two accumulation passes."""
+    if BLOCK_SKIPS:
+        return kernels.layer_norm_modulate(x, shift, scale, eps, skips=2)
+    return kernels.layer_norm_modulate(x, shift, scale, eps), x, x
+
+
 class MMDiTBlock(nn.Module):
     def __init__(self, dim: int, heads: int = 8, hidden_act: str = "silu", use_flash_attn: bool = False, use_rope: bool = False):
         super().__init__()
@@ -195,16 +209,17 @@ class MMDiTBlock(nn.Module):
         c_sh1, c_sc1, c_g1, c_sh2, c_sc2, c_g2 = self.modC(global_cond).chunk(6, dim=1)
         x_sh1, x_sc1, x_g1, x_sh2, x_sc2, x_g2 = self.modX(global_cond).chunk(6, dim=1)
         eps = self.normC1.eps
-        c_att, x_att = self.attn(kernels.layer_norm_modulate(condition, c_sh1, c_sc1, eps),
-                                 kernels.layer_norm_modulate(patches, x_sh1, x_sc1, eps), rope_freqs)
+        c_n1, c_skip1, c_skip2 = _norm_with_skips(condition, c_sh1, c_sc1, eps)
+        x_n1, x_skip1, x_skip2 = _norm_with_skips(patches, x_sh1, x_sc1, eps)
+        c_att, x_att = self.attn(c_n1, x_n1, rope_freqs)
         # stream C
-        c_mid = kernels.gate_residual(condition, c_g1, c_att)
+        c_mid = kernels.gate_residual(c_skip1, c_g1, c_att)
         c_mlp = self.mlpC(kernels.layer_norm_modulate(c_mid, c_sh2, c_sc2, eps))
-        condition = kernels.gate_residual(condition, c_g2, c_mlp)
+        condition = kernels.gate_residual(c_skip2, c_g2, c_mlp)
         # stream X
-        x_mid = kernels.gate_residual(patches, x_g1, x_att)
+        x_mid = kernels.gate_residual(x_skip1, x_g1, x_att)
         x_mlp = self.mlpX(kernels.layer_norm_modulate(x_mid, x_sh2, x_sc2, eps))
-        patches = kernels.gate_residual(patches, x_g2, x_mlp)
+        patches = kernels.gate_residual(x_skip2, x_g2, x_mlp)
         return condition, patches
 
 
@@ -220,10 +235,12 @@ class DiTBlock(nn.Module):
     def forward(self, context, global_cond, rope_freqs=None, **kwargs):
         sh1, sc1, g1, sh2, sc2, g2 = self.modCX(global_cond).chunk(6, dim=1)
         eps = self.norm1.eps
-        att = self.attn(kernels.layer_norm_modulate(context, sh1, sc1, eps), rope_freqs)
-        mid = kernels.gate_residual(context, g1, att)
+        # the block input feeds norm1 and BOTH gated adds: its three gradients meet inside norm1's backward kernel
+        n1, skip1, skip2 = _norm_with_skips(context, sh1, sc1, eps)
+        att = self.attn(n1, rope_freqs)
+        mid = kernels.gate_residual(skip1, g1, att)
         mlp = self.mlp(kernels.layer_norm_modulate(mid, sh2, sc2, eps))
-        return kernels.gate_residual(context, g2, mlp)
+        return kernels.gate_residual(skip2, g2, mlp)
 
 
 class TimestepEmbedder(nn.Module):
