@@ -419,6 +419,8 @@ def main():
     legs = {}
     if args.workload == "sdxl_lora" and not args.single:
         legs["aura_lora"] = run_workload("aura_lora", default_batch["aura_lora"], max(3, min(args.steps, 5)), 2)
+        if world == 1:  # BASELINE configs[1] (SDXL full fine-tune, 1 GPU): a third, single-GPU leg of the default run
+            legs["sdxl_full"] = run_workload("sdxl_full", default_batch["sdxl_full"], max(3, min(args.steps, 5)), 2)
 
     if rank == 0:
         out = {
