@@ -262,7 +262,7 @@ def main():
     from vision_ft_amd.trainer.dp import DataParallelGrads
 
     gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
-    default_batch = {"sdxl_lora": 24, "sdxl_full": 16, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4, "sdxl_buckets": 16}
+    default_batch = {"sdxl_lora": 24, "sdxl_full": 24, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4, "sdxl_buckets": 16}
 
     def fence():
         if world > 1:
