@@ -129,6 +129,12 @@ class GraphedTrainStep:
         torch.cuda.set_rng_state(rng)
 
     def _capture(self, pool, opt_graph) -> None:
+        # the warm-up's activations are cached blocks of the default pool; the capture allocates the same amount again in
+        # the graph's private pool — hand the cached blocks back first, or every step costs its memory twice
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, pool=pool):
             loss = self.forward_loss()
