@@ -180,7 +180,7 @@ int vft_conv3x3_wgrad(const void* dy, const void* x, void* dw, float* scratch, i
 int64_t vft_norm_bwd_params_scratch_floats(int64_t rows, int C);
 int vft_norm_bwd_params(const void* dy, const void* x, const void* scale, const float* mean, const float* rstd,
                         void* dw, void* db, float* scratch, int64_t rows, int C, int64_t ldx,
-                        int rows_per_batch, int kind, int out_f32, void* stream);
+                        int rows_per_batch, int kind, int out_f32, int accumulate /* dw, db += */, void* stream);
 
 /* out[c] (+)= sum over rows of dy[row][c]: the bias gradient of a trainable nn.Linear / nn.Conv2d (what autograd runs as
  * aten::sum; src/models/sdxl/denoiser.py:74,167,183-204,511-551 with trainable biases).  scratch:

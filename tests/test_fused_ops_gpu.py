@@ -63,6 +63,14 @@ def test_norm_parameter_gradients_many_slabs_and_reproducible(gpu):
         outs.append((ww.grad.clone(), bw.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel_err(outs[2][0].float().cpu(), outs[0][0].float().cpu()) < 4e-3
+    # a second backward accumulates into the existing gradients in place (no new tensors for autograd to add)
+    xw, ww, bw = x.to(gpu), w.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    kernels.layer_norm(xw, ww, bw, 1e-5).backward(gy)
+    pw, pb = ww.grad.data_ptr(), bw.grad.data_ptr()
+    kernels.layer_norm(xw, ww, bw, 1e-5).backward(gy)
+    assert ww.grad.data_ptr() == pw and bw.grad.data_ptr() == pb
+    assert rel_err(ww.grad.float().cpu(), 2 * outs[2][0].float().cpu()) < 6e-3
+    assert rel_err(bw.grad.float().cpu(), 2 * outs[2][1].float().cpu()) < 6e-3
 
 
 def test_layer_norm_modulate_and_rms_scale(gpu):

@@ -526,7 +526,7 @@ extern "C" int64_t vft_norm_bwd_params_scratch_floats(int64_t rows, int C) {
 
 extern "C" int vft_norm_bwd_params(const void* dy, const void* x, const void* scale, const float* mean, const float* rstd,
                                    void* dw, void* db, float* scratch, int64_t rows, int C, int64_t ldx,
-                                   int rows_per_batch, int kind, int out_f32, void* stream) {
+                                   int rows_per_batch, int kind, int out_f32, int accumulate, void* stream) {
     VFT_CHECK_ARG(dy && x && rstd && scratch && (dw || db), "vft_norm_bwd_params: null pointer");
     VFT_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0, "vft_norm_bwd_params: unsupported C=%d", C);
     VFT_CHECK_ARG(kind == KIND_RMS || mean != nullptr, "vft_norm_bwd_params: layer norm needs the saved mean");
@@ -534,7 +534,7 @@ extern "C" int vft_norm_bwd_params(const void* dy, const void* x, const void* sc
     NormParamGrad p{};
     p.dy = (const bf16_t*)dy, p.x = (const bf16_t*)x, p.scale = (const bf16_t*)scale, p.mean = mean, p.rstd = rstd;
     p.part = scratch, p.dw = dw, p.db = db, p.rows = rows, p.C = C, p.ldx = ldx, p.rpb = rows_per_batch > 0 ? rows_per_batch : 1;
-    p.kind = kind, p.out_f32 = out_f32, p.lddy = C;
+    p.kind = kind, p.out_f32 = out_f32, p.lddy = C, p.accumulate = accumulate;
     norm_param_slabs(rows, C, p.slab_rows, p.slabs);
     hipLaunchKernelGGL(norm_bwd_params_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)p.slabs), dim3(256), 0,
                        (hipStream_t)stream, p);

@@ -259,15 +259,19 @@ class _RowNorm(torch.autograd.Function):
             pdt = (weight if want_w else bias).dtype
             f32 = pdt != torch.bfloat16
             odt = torch.float32 if f32 else torch.bfloat16
-            dwk = torch.empty(C, dtype=odt, device=dy.device) if want_w else None
-            dbk = torch.empty(C, dtype=odt, device=dy.device) if want_b else None
+            # existing bf16 gradients (the trainer's flat buffer): accumulate in place, nothing left for autograd to add
+            gw, gb = (_grad_target(weight) if want_w else None), (_grad_target(bias) if want_b else None)
+            inplace = not f32 and (gw is not None or not want_w) and (gb is not None or not want_b)
+            dwk = (gw if inplace else torch.empty(C, dtype=odt, device=dy.device)) if want_w else None
+            dbk = (gb if inplace else torch.empty(C, dtype=odt, device=dy.device)) if want_b else None
             scratch = torch.empty(int(_C.lib().vft_norm_bwd_params_scratch_floats(rows, C)), dtype=torch.float32, device=dy.device)
             with torch.cuda.device(dy.device), _Timed("norm_bwd", 4.0 * rows * C):
                 st = _C.lib().vft_norm_bwd_params(_ptr(dy2), _ptr(x2), _ptr(sc), _ptr(mean), _ptr(rstd), _ptr(dwk), _ptr(dbk),
-                                                  _ptr(scratch), rows, C, x2.stride(0), rpb, kind, int(f32), _stream())
+                                                  _ptr(scratch), rows, C, x2.stride(0), rpb, kind, int(f32), int(inplace), _stream())
             _C.check(st, "vft_norm_bwd_params")
-            dw = dwk.to(weight.dtype) if want_w else None
-            db = dbk.to(bias.dtype) if want_b else None
+            if not inplace:
+                dw = dwk.to(weight.dtype) if want_w else None
+                db = dbk.to(bias.dtype) if want_b else None
         if any(ctx.needs_input_grad[3:5]):
             xf = x2.float()
             xh = (xf - mean[:, None]) * rstd[:, None] if kind == KIND_LAYER else xf * rstd[:, None]
