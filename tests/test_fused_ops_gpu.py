@@ -244,7 +244,8 @@ def test_group_norm_is_bit_reproducible(gpu, nhwc):
     assert rel_err(runs[0][2].float(), wf.grad) < 1e-2 and rel_err(runs[0][3].float(), bf.grad) < 1e-2
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 640, 320, 32, 24), (3, 1920, 640, 16, 16), (1, 960, 320, 20, 36)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 640, 320, 32, 24), (3, 1920, 640, 16, 16), (1, 960, 320, 20, 36),
+                                            (4, 640, 320, 32, 32)])  # the last: 4 096 pixels -> vft_linear_wgrad / vft_colsum
 def test_conv1x1_with_fused_add(gpu, B, Cin, Cout, H, W):
     """ResidualBlock's skip convolution + `h + skip(x)` as one projection-GEMM launch (channels-last), forward, data
     gradient, weight / bias gradients and the add's gradient, against fp32 math on the same bf16 operands."""
@@ -268,6 +269,8 @@ def test_conv1x1_with_fused_add(gpu, B, Cin, Cout, H, W):
     assert rel_err(x.grad.float(), xf.grad) < 6e-3
     assert rel_err(w.grad.float(), wf.grad) < 1e-2 and rel_err(b.grad.float(), bf.grad) < 1e-2
     assert torch.equal(h.grad, dy)
+    kernels.conv1x1(x, w, b, add=h).backward(dy)  # existing gradients: accumulated (in place where the kernels take them)
+    assert rel_err(w.grad.float(), 2 * wf.grad) < 1.5e-2 and rel_err(b.grad.float(), 2 * bf.grad) < 1.5e-2
 
 
 def test_plain_linear_on_the_fused_gemm(gpu):

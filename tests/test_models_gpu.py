@@ -324,3 +324,69 @@ def test_lumina2_denoiser_parity(gpu):
         lambda m: loss_with_predicted_velocity(g["latents"], g["noise"], call(m, T["noisy"].to(gpu)).float()),
         json.loads(meta["lora_keys"]))
     torch.testing.assert_close(losses, T["lora.losses"], rtol=LOSS_RTOL, atol=0)
+
+
+def test_sdxl_full_finetune_gradients_through_the_weight_gradient_kernels(gpu):
+    """BASELINE config 2 (every weight trainable) at sizes where the full fine-tune's own kernels take over: 4 x 64x64
+    latents on the tiny UNet put the level-0 3x3 convolutions (16 384 pixels) on vft_conv3x3_wgrad, the level-1 attention /
+    FeedForward projections (4 096 tokens) on vft_linear_wgrad, biases on vft_colsum and the LayerNorm parameters on
+    vft_norm_bwd_params.  EVERY parameter gradient is compared with the oracle's fp32 truth (as close as the reference's own
+    bf16-autocast numerics, x2 slack, or 3e-2); a second backward must accumulate in place (gradients double)."""
+    from vision_ft_amd.models.sdxl import Denoiser, DenoiserConfig
+    from vision_ft_amd.modules.loss.diffusion import loss_with_predicted_noise
+
+    _, meta = load_golden("sdxl_tiny.safetensors")
+    cfgd = json.loads(meta["config"])
+    with torch.device("meta"):
+        shape_mod = Denoiser(DenoiserConfig(**cfgd))
+    P = synth_params(shape_mod, 0, meta["checksum"])
+    Pb = {k: v.to(torch.bfloat16).float() for k, v in P.items()}
+    cfg = osdxl.SDXLCfg(**cfgd)
+    g0 = torch.Generator().manual_seed(123)
+    B, H, W = 4, 64, 64
+    rb = lambda *s: torch.randn(*s, generator=g0).to(torch.bfloat16).float()  # noqa: E731
+    noisy, noise, lat = rb(B, 4, H, W), rb(B, 4, H, W), rb(B, 4, H, W)
+    ehs, pooled = rb(B, 11, cfgd["context_dim"]), rb(B, 1280)
+    timestep = torch.tensor([10, 300, 620, 990])
+    size = torch.tensor([[H * 8, W * 8]] * B)
+    crop = torch.zeros(B, 2, dtype=torch.long)
+    names = list(Pb)
+
+    def oracle_loss(P_, x_):
+        return ops.ddpm_loss(noise, osdxl.unet_forward(P_, cfg, x_, timestep, ehs, pooled, size, size, crop))
+
+    Po = {k: v.clone().requires_grad_(True) for k, v in Pb.items()}
+    with autocast_cpu():
+        loss_o = oracle_loss(Po, noisy)
+    loss_o.backward()
+    tg, _, _ = _truth_grads(oracle_loss, Pb, names, noisy)
+
+    model = _to_gpu_module(Denoiser, DenoiserConfig(**cfgd), Pb, gpu)
+    model.requires_grad_(True)
+    model.train()
+    dev = {k: v.to(gpu) for k, v in dict(timestep=timestep, ehs=ehs.to(torch.bfloat16), pooled=pooled.to(torch.bfloat16),
+                                         size=size, crop=crop, noise=noise, lat=lat).items()}
+
+    def gpu_loss():
+        out = model(latents=noisy.to(gpu, torch.bfloat16), timestep=dev["timestep"], encoder_hidden_states=dev["ehs"],
+                    encoder_pooler_output=dev["pooled"], original_size=dev["size"], target_size=dev["size"],
+                    crop_coords_top_left=dev["crop"])
+        return loss_with_predicted_noise(dev["lat"], dev["noise"], out.float())
+
+    loss = gpu_loss()
+    loss.backward()
+    torch.testing.assert_close(loss.cpu().float(), loss_o.float(), rtol=LOSS_RTOL, atol=0)
+    _check_grads(model, {n: Po[n].grad for n in names if Po[n].grad is not None},
+                 {n: t for n, t in tg.items() if t is not None})
+    first = {n: p.grad.clone() for n, p in model.named_parameters()}
+    from vision_ft_amd import kernels
+
+    kernels.set_profiling(True)
+    gpu_loss().backward()
+    torch.cuda.synchronize()
+    ran = set(kernels.profile_report())
+    kernels.set_profiling(False)
+    assert {"linear_wgrad", "conv3x3_wgrad", "colsum"} <= ran, ran  # the kernels under test really ran
+    for n, p in model.named_parameters():
+        e = rel_err(p.grad.float().cpu(), 2 * first[n].float().cpu())
+        assert e < 2e-2, (n, e)

@@ -1825,6 +1825,7 @@ class _Conv1x1(torch.autograd.Function):
         linear_fused(x2, w2, _bf16_or_none(bias), residual=a2, out=y.permute(0, 2, 3, 1).reshape(-1, Cout))
         ctx.save_for_backward(x2, weight)
         ctx.shape, ctx.has_bias, ctx.has_add = (B, Cin, H, W), bias is not None, add is not None
+        ctx.wparam, ctx.bparam = weight, bias
         return y
 
     @staticmethod
@@ -1839,10 +1840,21 @@ class _Conv1x1(torch.autograd.Function):
             dx = torch.empty((B, Cin, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
             wt = weight.detach().reshape(Cout, Cin).t().contiguous() if weight.requires_grad else _conv1x1_wt(weight)
             linear_fused(dy2, wt, None, out=dx.permute(0, 2, 3, 1).reshape(-1, Cin))
-        if ctx.needs_input_grad[1]:  # full fine-tune: plain library GEMM over the pixels
-            dw = (dy2.t() @ x2).reshape(weight.shape).to(weight.dtype)
+        if ctx.needs_input_grad[1]:  # full fine-tune: the projection weight-gradient kernel over the pixel rows
+            if _wgrad_on_kernel(dy2.shape[0], Cout, Cin) and dy2.shape[0] >= 4096 and linear_wgrad_eligible(dy2, x2):
+                g = getattr(ctx.wparam, "grad", None)
+                g2 = g.reshape(Cout, Cin) if (g is not None and g.dtype == torch.bfloat16 and g.is_cuda and g.shape == weight.shape
+                                              and g.reshape(Cout, Cin).data_ptr() == g.data_ptr()
+                                              and g.reshape(Cout, Cin).is_contiguous() and g.data_ptr() % 16 == 0) else None
+                with torch.cuda.device(dy.device):
+                    if g2 is not None:
+                        linear_wgrad(dy2, x2, out=g2, accumulate=True)
+                    else:
+                        dw = linear_wgrad(dy2, x2).reshape(weight.shape).to(weight.dtype)
+            else:
+                dw = (dy2.t() @ x2).reshape(weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.float().sum(0).to(dy.dtype)
+            db = colsum(dy2, ctx.bparam)
         return dx, dw, db, (dy if ctx.has_add and ctx.needs_input_grad[3] else None)
 
 
