@@ -117,8 +117,11 @@ def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int
         def fwd():
             t = uniform_rand(lat.shape, device)
             noisy, noise = LF.prepare_noised_latents(lat, (1 - t).to(lat.dtype))
-            out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask)
-            pred = -torch.nested.to_padded_tensor(out, padding=0.0)
+            # caption lengths as host integers (a data loader knows them before the batch goes to the device): without them the
+            # model reads them back from the mask — the step's only host synchronisation, which also rules out graph replay
+            out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask, caption_lengths=[256] * batch,
+                              padded_output=True)
+            pred = -out
             return LF.loss_with_predicted_velocity(lat.float(), noise.float(), pred.float())
     return fwd
 
@@ -275,7 +278,7 @@ def main():
         model = build(workload, device)
         params = [p for p in model.parameters() if p.requires_grad]
         dp = DataParallelGrads(params)
-        use_graph = not args.no_graph and not workload.startswith("lumina")  # Lumina2's ragged assembly reads lengths on the host
+        use_graph = not args.no_graph
         opt = torch.optim.AdamW(params, lr=1e-3, fused=True, capturable=use_graph)
         fwd = make_step(workload, model, device, batch, seed=42 + rank)
 

@@ -318,6 +318,43 @@ def test_lumina2_denoiser_parity(gpu):
     # refined caption features: only the valid (unpadded) rows are ever consumed downstream
     for i, n in enumerate(T["caption_mask"].sum(-1).tolist()):
         assert rel_err(capf[i, :n].cpu(), T["ragged.caption_features"][i, :n]) < TENSOR_TOL
+    # caption lengths handed over as host integers (no read-back from the mask) + the directly padded output: the same
+    # bits as the default path, for the uniform and for the two-resolution batch, and the whole forward / backward can then
+    # be captured into a HIP graph whose replay gives the eager result
+    lens = T["caption_mask"].sum(-1).tolist()
+    with torch.no_grad():
+        o3, _, _ = model(latents=[T["ragged.in0"].to(gpu), T["ragged.in1"].to(gpu)], timestep=g["timestep"],
+                         caption_features=g["caption"], caption_mask=g["caption_mask"], caption_lengths=lens, padded_output=True)
+        assert torch.equal(o3, torch.nested.to_padded_tensor(o2, padding=0.0))
+        o4, _, _ = model(latents=T["noisy"].to(gpu), timestep=g["timestep"], caption_features=g["caption"],
+                         caption_mask=g["caption_mask"], caption_lengths=lens, padded_output=True)
+        assert torch.equal(-o4, call(model, T["noisy"].to(gpu)))
+    xs = T["noisy"].to(gpu).clone().requires_grad_(True)
+    xs.grad = torch.zeros_like(xs)
+    model.requires_grad_(False)  # frozen trunk, as under LoRA: the input gradient is what the capture has to reproduce
+
+    def fb():
+        o, _, _ = model(latents=xs, timestep=g["timestep"], caption_features=g["caption"], caption_mask=g["caption_mask"],
+                        caption_lengths=lens, padded_output=True)
+        loss_with_predicted_velocity(g["latents"], g["noise"], (-o).float()).backward()
+        return o.detach()
+
+    eager_out = fb().clone()
+    eager_grad = xs.grad.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fb()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = fb()
+    xs.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, eager_out) and torch.equal(xs.grad, eager_grad)
+    model.requires_grad_(True)
 
     losses = _lora_train_gpu(
         model, ["attention", "feed_forward"],

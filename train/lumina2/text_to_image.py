@@ -63,8 +63,10 @@ class Lumina2ForTextToImageTraining(DenoiserTask):
         # reference forward_and_loss :100-142: Lumina2 time runs 0 (noise) -> 1 (clean); prediction sign flipped
         t = self.sample_timesteps(latents.shape)
         noisy, noise = prepare_noised_latents(latents, (1 - t).to(latents.dtype))
-        out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"])
-        pred = -torch.nested.to_padded_tensor(out, padding=0.0)
+        out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"],
+                               caption_lengths=cond.get("caption_lengths"),  # host integers when the producer has them
+                               padded_output=True)  # = to_padded_tensor(nested output, 0.0), capturable
+        pred = -out
         loss = loss_with_predicted_velocity(latents, noise, pred)
         if self.model_config.use_downsampled_velocity_loss:
             loss = loss + F.mse_loss(F.avg_pool2d(pred.float(), 4, 4), F.avg_pool2d((noise - latents).float(), 4, 4))

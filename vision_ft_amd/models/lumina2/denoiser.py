@@ -222,15 +222,16 @@ class ImageSize(NamedTuple):
         return [cls(height=int(h), width=int(w)) for h, w in sizes.tolist()]
 
 
-def _pad_rows(items: list[torch.Tensor], device) -> tuple[torch.Tensor, torch.Tensor, list[int]]:
-    """zero-pad along dim 0 and stack; returns (padded, prefix bool mask, lengths)."""
+def _pad_rows(items: list[torch.Tensor], device, want_mask: bool = True) -> tuple[torch.Tensor, torch.Tensor | None, list[int]]:
+    """zero-pad along dim 0 and stack; returns (padded, prefix bool mask, lengths).  want_mask=False skips the mask (its
+    construction copies the lengths to the device — not allowed while a HIP graph is being captured)."""
     lens = [int(t.size(0)) for t in items]
     mx = max(lens)
     if all(n == mx for n in lens):
         padded = torch.stack(items, dim=0)
     else:
         padded = torch.stack([F.pad(t, [0, 0] * (t.dim() - 1) + [0, mx - t.size(0)]) for t in items], dim=0)
-    mask = torch.arange(mx, device=device).unsqueeze(0) < torch.tensor(lens, device=device).unsqueeze(1)
+    mask = (torch.arange(mx, device=device).unsqueeze(0) < torch.tensor(lens, device=device).unsqueeze(1)) if want_mask else None
     return padded, mask, lens
 
 
@@ -272,9 +273,16 @@ class NextDiT(nn.Module):
         grid = patches.reshape(gh, gw, patch_size, patch_size, out_channels).permute(4, 0, 2, 1, 3)
         return grid.reshape(out_channels, gh * patch_size, gw * patch_size)
 
-    def nested_unpatchify(self, patches, image_sizes: list[ImageSize]) -> torch.Tensor:
+    def nested_unpatchify(self, patches, image_sizes: list[ImageSize], padded: bool = False) -> torch.Tensor:
         images = [self.unpatchify(p, latent_height=s.height, latent_width=s.width, patch_size=self.patch_size,
                                   out_channels=self.out_channels) for p, s in zip(patches, image_sizes)]
+        if padded:
+            # what torch.nested.to_padded_tensor(nested, 0.0) returns, built directly: the nested tensor's backward copies its
+            # size table from the host, which a HIP-graph capture does not allow
+            mh, mw = max(s.height for s in image_sizes), max(s.width for s in image_sizes)
+            if all(s.height == mh and s.width == mw for s in image_sizes):
+                return torch.stack(images, dim=0)
+            return torch.stack([F.pad(im, [0, mw - im.shape[-1], 0, mh - im.shape[-2]]) for im in images], dim=0)
         return torch.nested.as_nested_tensor(images)
 
     @torch.no_grad()
@@ -310,58 +318,87 @@ class NextDiT(nn.Module):
             return checkpoint(layer, x, rope, t, mask, kv_len, use_reentrant=False)
         return layer(x, rope, adaln_input=t, mask=mask, kv_len=kv_len)
 
-    def forward(self, latents, caption_features, timestep: torch.Tensor, caption_mask, cached_caption_features=None):
+    def _layout(self, cap_lens: tuple[int, ...], sizes: tuple[ImageSize, ...], cap_rows: int, dev) -> dict:
+        """Device-resident constants of one (caption lengths, image sizes) combination — position ids -> rotary tables of
+        the [caption | image] sequences, their caption / image row subsets, the three length vectors and the caption prefix
+        mask — built once and kept (16 most recent combinations): nothing of this depends on the step's data, and with it
+        cached a forward pass copies nothing from the host, so it can be captured into a HIP graph."""
+        key = (cap_lens, sizes, cap_rows, str(dev))
+        cache = self.__dict__.setdefault("_layouts", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        p = self.patch_size
+        b = len(cap_lens)
+        img_lens = [(s.height // p) * (s.width // p) for s in sizes]
+        tot_lens = [c + n for c, n in zip(cap_lens, img_lens)]
+        max_len = max(tot_lens)
+        with torch.no_grad():
+            # position ids for [caption | image] per sample, padded to the longest sample
+            ids = torch.zeros(b, max_len, 3, dtype=torch.int32, device=dev)
+            for i, (cl, s) in enumerate(zip(cap_lens, sizes)):
+                ids[i, : tot_lens[i]] = self.get_position_ids(cl, s.height // p, s.width // p, device=dev)
+            rope = self.rope_embedder(ids)
+            len_t = lambda L: torch.tensor(L, dtype=torch.int32, device=dev)  # noqa: E731
+            mc, mi = max(cap_lens), max(img_lens)
+            gather = torch.zeros(b, mi, dtype=torch.long, device=dev)
+            for i in range(b):
+                gather[i, : img_lens[i]] = torch.arange(cap_lens[i], cap_lens[i] + img_lens[i], device=dev)
+            hit = {
+                "rope": rope,
+                "cap_rope": Rope(rope.cos[:, :mc].contiguous(), rope.sin[:, :mc].contiguous()),  # caption rows come first
+                "img_rope": Rope(torch.gather(rope.cos, 1, gather.unsqueeze(-1).expand(-1, -1, rope.cos.shape[-1])),
+                                 torch.gather(rope.sin, 1, gather.unsqueeze(-1).expand(-1, -1, rope.sin.shape[-1]))),
+                "ck": len_t(list(cap_lens)), "ik": len_t(img_lens), "tk": len_t(tot_lens),
+                "cap_mask": torch.arange(cap_rows, device=dev).unsqueeze(0) < len_t(list(cap_lens)).unsqueeze(1),
+                "img_lens": img_lens, "tot_lens": tot_lens, "max_len": max_len,
+            }
+        if len(cache) >= 16:
+            cache.pop(next(iter(cache)))
+        cache[key] = hit
+        return hit
+
+    def forward(self, latents, caption_features, timestep: torch.Tensor, caption_mask, cached_caption_features=None,
+                caption_lengths: list[int] | None = None, padded_output: bool = False):
+        """`caption_lengths`: the number of valid caption tokens per sample as host integers, when the caller has them
+        (the data loader knows them before the batch goes to the device); without them they are read back from
+        `caption_mask` — the forward pass's only host synchronisation.  `padded_output`: return the images zero-padded to
+        the largest one and stacked (= `torch.nested.to_padded_tensor(out, 0.0)` of the default nested output)."""
         dev = timestep.device
         dtype = module_dtype(self.x_embedder)
         images = list(latents.unbind()) if isinstance(latents, torch.Tensor) else list(latents)
         b = len(images)
         p = self.patch_size
 
-        cmask = caption_mask if isinstance(caption_mask, torch.Tensor) else _pad_rows([m.bool() for m in caption_mask], dev)[0]
-        cmask = cmask.bool()
-        cap_lens: list[int] = cmask.sum(dim=-1).tolist()  # the step's single host sync
+        if caption_lengths is not None:
+            cap_lens = [int(n) for n in caption_lengths]
+        else:
+            cmask = caption_mask if isinstance(caption_mask, torch.Tensor) else _pad_rows([m.bool() for m in caption_mask], dev)[0]
+            cap_lens = cmask.bool().sum(dim=-1).tolist()  # the step's single host sync
         sizes = [ImageSize(int(im.shape[-2]), int(im.shape[-1])) for im in images]
-        img_lens = [(s.height // p) * (s.width // p) for s in sizes]
-        tot_lens = [c + n for c, n in zip(cap_lens, img_lens)]
-        max_len = max(tot_lens)
+        cap_rows = cached_caption_features.shape[1] if cached_caption_features is not None else max(cap_lens)
+        lay = self._layout(tuple(cap_lens), tuple(sizes), int(cap_rows), dev)
+        img_lens, tot_lens, max_len, rope = lay["img_lens"], lay["tot_lens"], lay["max_len"], lay["rope"]
 
         t = self.t_embedder(timestep)
 
-        # position ids for [caption | image] per sample, padded to the longest sample
-        ids = torch.zeros(b, max_len, 3, dtype=torch.int32, device=dev)
-        for i, (cl, s) in enumerate(zip(cap_lens, sizes)):
-            ids[i, : tot_lens[i]] = self.get_position_ids(cl, s.height // p, s.width // p, device=dev)
-        rope = self.rope_embedder(ids)
-        len_t = lambda L: torch.tensor(L, dtype=torch.int32, device=dev)  # noqa: E731
-        overall_mask = torch.arange(max_len, device=dev).unsqueeze(0) < len_t(tot_lens).unsqueeze(1)
-
         # caption refiner (no AdaLN)
+        cap_mask = lay["cap_mask"]
         if cached_caption_features is not None:
             cap = cached_caption_features
-            cap_mask = torch.arange(cap.shape[1], device=dev).unsqueeze(0) < len_t(cap_lens).unsqueeze(1)
         else:
             # prefix masks: the valid caption rows of sample i are rows [0, cap_lens[i])
-            cap_in, cap_mask, _ = _pad_rows([caption_features[i][: cap_lens[i]] for i in range(b)], dev)
-            mc = cap_in.shape[1]
-            cap_rope = Rope(rope.cos[:, :mc], rope.sin[:, :mc])  # caption rows come first in every sample
+            cap_in, _, _ = _pad_rows([caption_features[i][: cap_lens[i]] for i in range(b)], dev, want_mask=False)
             cap = self.cap_embedder[1](kernels.rms_norm_scale(cap_in.to(dtype), self.cap_embedder[0].weight, None,
                                                               self.cap_embedder[0].eps))
-            ck = len_t(cap_lens)
             for layer in self.context_refiner:
-                cap = self._run(layer, cap, cap_rope, None, None, ck)
+                cap = self._run(layer, cap, lay["cap_rope"], None, None, lay["ck"])
 
         # noise refiner
-        patches, img_mask, _ = _pad_rows([self.patchify(im.to(dtype)) for im in images], dev)
-        mi = patches.shape[1]
-        gather = torch.zeros(b, mi, dtype=torch.long, device=dev)
-        for i in range(b):
-            gather[i, : img_lens[i]] = torch.arange(cap_lens[i], cap_lens[i] + img_lens[i], device=dev)
-        img_rope = Rope(torch.gather(rope.cos, 1, gather.unsqueeze(-1).expand(-1, -1, rope.cos.shape[-1])),
-                        torch.gather(rope.sin, 1, gather.unsqueeze(-1).expand(-1, -1, rope.sin.shape[-1])))
+        patches, _, _ = _pad_rows([self.patchify(im.to(dtype)) for im in images], dev, want_mask=False)
         x = self.x_embedder(patches)
-        ik = len_t(img_lens)
         for layer in self.noise_refiner:
-            x = self._run(layer, x, img_rope, t, None, ik)
+            x = self._run(layer, x, lay["img_rope"], t, None, lay["ik"])
 
         # [caption | image] per sample
         ctx = torch.zeros(b, max_len, cap.shape[-1], dtype=cap.dtype, device=dev)
@@ -369,13 +406,12 @@ class NextDiT(nn.Module):
             ctx[i, : cap_lens[i]] = cap[i, : cap_lens[i]]
             ctx[i, cap_lens[i] : tot_lens[i]] = x[i, : img_lens[i]]
 
-        tk = len_t(tot_lens)
         for layer in self.layers:
-            ctx = self._run(layer, ctx, rope, t, None, tk)
+            ctx = self._run(layer, ctx, rope, t, None, lay["tk"])
 
         out = self.final_layer(ctx, t)
         pieces = [out[i, cap_lens[i] : tot_lens[i]] for i in range(b)]
-        return self.nested_unpatchify(pieces, sizes), cap_mask, cap
+        return self.nested_unpatchify(pieces, sizes, padded=padded_output), cap_mask, cap
 
 
 class Denoiser(NextDiT):
