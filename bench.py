@@ -424,6 +424,8 @@ def main():
         legs["aura_lora"] = run_workload("aura_lora", default_batch["aura_lora"], max(3, min(args.steps, 5)), 2)
         if world == 1:  # BASELINE configs[1] (SDXL full fine-tune, 1 GPU): a third, single-GPU leg of the default run
             legs["sdxl_full"] = run_workload("sdxl_full", default_batch["sdxl_full"], max(3, min(args.steps, 5)), 2)
+            # BASELINE configs[3] (Lumina-Image-2.0 NextDiT QLoRA: NF4 base + bf16 LoRA)
+            legs["lumina_qlora"] = run_workload("lumina_qlora", default_batch["lumina_qlora"], max(3, min(args.steps, 5)), 2)
 
     if rank == 0:
         out = {
