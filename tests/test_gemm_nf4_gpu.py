@@ -348,7 +348,7 @@ def test_every_tile_variant_gives_the_same_bits(gpu):
 
 
 @pytest.mark.parametrize("M,R,Cc", [(1000, 640, 640), (16384, 1280, 1280), (4097, 320, 2560), (70, 8, 8), (5000, 264, 136),
-                                    (24576, 2560, 640)])
+                                    (24576, 2560, 640), (40, 72, 264), (129, 1280, 8)])
 def test_linear_wgrad_matches_fp32(gpu, M, R, Cc):
     """vft_linear_wgrad (dW = dyᵀ·x, the trainable projection's weight gradient: transposed LDS reads, split reduction
     with ordered partial sums) against the fp32 product; tolerance: bf16 rounding of the output (rel L2 < 5e-3)."""
