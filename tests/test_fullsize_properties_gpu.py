@@ -126,3 +126,36 @@ def test_nf4_gemm_equals_bf16_gemm_on_dequantised_weight_at_full_size(gpu):
     st = layer.quant_state()
     assert rel_err(kernels._nf4_gemm(x, st, None, False), (x.float() @ wd.float().t())) < 4e-3
     assert rel_err(kernels._nf4_gemm(gy, st, None, True), (gy.float() @ wd.float())) < 4e-3
+
+
+def test_weight_gradient_kernels_at_full_size(gpu):
+    """vft_linear_wgrad / vft_conv3x3_wgrad at the full fine-tune's bench sizes (BASELINE config 2), checked without a CPU
+    product: (1) every tap block of the convolution's weight gradient is the linear weight gradient of dy against the
+    correspondingly shifted activation — the centre tap with the unshifted one; (2) the sum of all entries equals
+    sum_m rowsum(dy)[m] * rowsum(x)[m]; (3) linearity in x; (4) bit-identical repeats (ordered partial sums)."""
+    from vision_ft_amd import kernels
+
+    # projections: the 64x64-latent attention weights (98 304 tokens, 640 x 640) and the 32x32-latent ones
+    for M, R, Cc, seed in ((98304, 640, 640, 20), (24576, 1280, 1280, 21)):
+        dy, x1, x2 = _bf(gpu, M, R, sc=M**-0.5, seed=seed), _bf(gpu, M, Cc, seed=seed + 100), _bf(gpu, M, Cc, seed=seed + 200)
+        d1, d2 = kernels.linear_wgrad(dy, x1), kernels.linear_wgrad(dy, x2)
+        d12 = kernels.linear_wgrad(dy, (x1.float() + x2.float()).to(torch.bfloat16))
+        assert rel_err(d12, d1.float() + d2.float()) < 1e-2  # linear in x (bf16 rounding of x1 + x2 and of the outputs)
+        total = (dy.float().sum(1).double() * x1.float().sum(1).double()).sum()
+        o32 = torch.empty(R, Cc, dtype=torch.float32, device=gpu)
+        kernels.linear_wgrad(dy, x1, out=o32)
+        assert abs(o32.double().sum() - total) < 2e-3 * (o32.double().abs().sum() ** 0.5 + 1)
+        assert torch.equal(d1, kernels.linear_wgrad(dy, x1))
+    # 3x3 convolution 320 -> 320 at 128x128, per-GPU batch 16
+    B, C, H = 16, 320, 128
+    x = _bf(gpu, B, C, H, H, seed=30).contiguous(memory_format=torch.channels_last)
+    gy = _bf(gpu, B, C, H, H, sc=(B * H * H) ** -0.5, seed=31).contiguous(memory_format=torch.channels_last)
+    dw = kernels.conv3x3_wgrad(gy, x).view(C, 3, 3, C)
+    gy2 = gy.permute(0, 2, 3, 1).reshape(-1, C)
+    centre = kernels.linear_wgrad(gy2, x.permute(0, 2, 3, 1).reshape(-1, C))
+    assert rel_err(dw[:, 1, 1, :], centre.float()) < 4e-3
+    shifted = torch.zeros_like(x)
+    shifted[:, :, 1:, :-1] = x[:, :, :-1, 1:]  # tap (kh, kw) = (0, 2): x[oh - 1, ow + 1], zero beyond the border
+    corner = kernels.linear_wgrad(gy2, shifted.permute(0, 2, 3, 1).reshape(-1, C))
+    assert rel_err(dw[:, 0, 2, :], corner.float()) < 4e-3
+    assert torch.equal(dw, kernels.conv3x3_wgrad(gy, x).view(C, 3, 3, C))
