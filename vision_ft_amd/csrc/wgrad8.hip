@@ -366,9 +366,10 @@ int pick_slices(int64_t M, int R, int halves) {
     const int nkt = (int)((M + 63) / 64);
     int best = 1;
     double bc = 1e30;
+    const double item_cost = 24.0;  // prologue + fp32 partial tile + its share of the reduce pass, in reduction steps (swept 4-24 on the SDXL shapes)
     for (int s = 1; s <= 64 && s * 4 <= nkt; ++s) {
         const int rounds = (ntiles * s + SLOTS - 1) / SLOTS;
-        const double c = rounds * ((double)((nkt + s - 1) / s) + 8.0) + 0.35 * s;  // last term: the reduce pass reads s partials
+        const double c = rounds * ((double)((nkt + s - 1) / s) + item_cost) + 0.35 * s;  // last term: the reduce pass reads s partials
         if (c < bc) bc = c, best = s;
     }
     return best;
