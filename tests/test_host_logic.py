@@ -208,6 +208,35 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.vft_version() >= 100
 
 
+def test_weight_gradient_scratch_sizes_and_argument_checks():
+    """Host-side parts of the weight-gradient entry points (no GPU): the scratch sizes are a whole number of fp32 partial
+    outputs (slices x R x Cc, 1 <= slices <= 64; one slice for reductions too short to split), grow with nothing but the
+    output size once the slice count saturates, and bad arguments are rejected before any launch."""
+    import ctypes
+
+    from vision_ft_amd import _C
+
+    lib = _C.lib()
+    for M, R, Cc in [(16384, 1280, 1280), (98304, 640, 640), (65536, 5120, 640), (100, 640, 640), (262144, 320, 320)]:
+        n = lib.vft_linear_wgrad_scratch_floats(M, R, Cc)
+        assert n > 0 and n % (R * Cc) == 0 and 1 <= n // (R * Cc) <= 64, (M, R, Cc, n)
+    assert lib.vft_linear_wgrad_scratch_floats(100, 640, 640) == 640 * 640          # 2 reduction tiles: not split
+    assert lib.vft_linear_wgrad_scratch_floats(16384, 1280, 1280) > 4 * 1280 * 1280  # 25 tiles on 256 CUs: split
+    nc = lib.vft_conv3x3_wgrad_scratch_floats(16 * 64 * 64, 640, 640)
+    assert nc > 0 and nc % (640 * 9 * 640) == 0
+    assert lib.vft_linear_wgrad_scratch_floats(0, 640, 640) == 0 and lib.vft_norm_bwd_params_scratch_floats(0, 640) == 0
+    ns = lib.vft_norm_bwd_params_scratch_floats(98304, 640)
+    assert ns > 0 and ns % (2 * 640) == 0
+    z = ctypes.c_void_p(0)
+    assert lib.vft_linear_wgrad(z, z, z, z, 1024, 640, 640, 640, 640, 640, 0, 0, z) == 1 and b"null" in lib.vft_last_error()
+    one = ctypes.c_void_p(16)
+    assert lib.vft_linear_wgrad(one, one, one, one, 1024, 636, 640, 640, 640, 640, 0, 0, z) == 1  # R % 8
+    assert lib.vft_conv3x3_wgrad(one, one, one, one, 2, 30, 30, 64, 64, 0, 0, z) == 1             # W % 8
+    assert b"W % 8" in lib.vft_last_error()
+    assert lib.vft_colsum(one, one, one, 1024, 644, 644, 0, 0, z) == 1                             # C % 8
+    assert lib.vft_norm_bwd_params(one, one, z, z, z, one, one, one, 1024, 640, 640, 1024, 0, 0, 0, z) == 1  # layer norm without mean
+
+
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     import ctypes
 
