@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from vision_ft_amd import _C, kernels  # noqa: E402
 
-BATCH = {"sdxl_lora": 24, "sdxl_full": 16, "sdxl_buckets": 8, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4}  # bench.py defaults
+BATCH = {"sdxl_lora": 24, "sdxl_full": 24, "sdxl_buckets": 16, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4}  # bench.py defaults
 BUCKETS = [(640, 1536), (768, 1280), (768, 1408), (896, 1152), (1024, 1024), (1152, 896), (1280, 768), (1408, 768), (1536, 640)]
 
 
