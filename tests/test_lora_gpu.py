@@ -406,3 +406,56 @@ def test_grouped_kv_projection_matches_separate_layers(gpu, lora_path):
     assert rel_err(got[0].float(), ref[0].float()) < 6e-3
     for g_, r_ in zip(got[1:], ref[1:]):
         assert rel_err(g_.float(), r_.float()) < 2e-3
+
+
+def test_adapter_applied_twice_in_one_backward_keeps_both_contributions(gpu, lora_path):
+    """One LoRA layer called twice before a single backward() (a module reused in a forward pass, or two forward passes
+    summed into one loss — the reference Lumina2 low-res + high-res loss, train/lumina2/text_to_image.py:207-216): with
+    gradient tensors in place both calls queue a deferred reduction into the SAME `.grad`; the queue must not let the two
+    table entries race.  Checked against the two gradients computed one call at a time."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator(device=gpu).manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu).to(torch.bfloat16)  # noqa: E731
+    A, B = (rn(4, 640) * 0.04).requires_grad_(), (rn(1280, 4) * 0.3).requires_grad_()
+    base = torch.nn.Linear(640, 1280, bias=False, device=gpu, dtype=torch.bfloat16).requires_grad_(False)
+    x1, x2 = rn(2048, 640), rn(1536, 640)
+    dy1, dy2 = rn(2048, 1280), rn(1536, 1280)
+    singles = []
+    for x, dy in ((x1, dy1), (x2, dy2)):
+        y = kernels.lora_linear(x, base, A, B, 0.25)
+        singles.append(torch.autograd.grad(y, (A, B), dy))
+    want_a = singles[0][0].float() + singles[1][0].float()
+    want_b = singles[0][1].float() + singles[1][1].float()
+    for trial in range(3):  # a lost update is a race: give it a few chances
+        A.grad, B.grad = torch.zeros_like(A), torch.zeros_like(B)
+        ya = kernels.lora_linear(x1, base, A, B, 0.25)
+        yb = kernels.lora_linear(x2, base, A, B, 0.25)
+        torch.autograd.backward((ya, yb), (dy1, dy2))
+        torch.cuda.synchronize()
+        assert rel_err(A.grad.float(), want_a) < 6e-3, (trial, rel_err(A.grad.float(), want_a))
+        assert rel_err(B.grad.float(), want_b) < 6e-3, (trial, rel_err(B.grad.float(), want_b))
+
+
+def test_grouped_entry_points_refuse_fp32_adapters(gpu, lora_path):
+    """`peft.config.dtype: float32` is schema-valid; the grouped kernels read raw bf16 pointers, so they must fall back
+    (lora_siblings / lora_group -> None) or raise (lora_qkv) instead of computing garbage."""
+    from types import SimpleNamespace
+
+    from vision_ft_amd import kernels
+
+    rn = lambda *s, dt=torch.bfloat16: torch.randn(*s, device=gpu).to(dt)  # noqa: E731
+    x = rn(2, 512, 640)
+    wcat = rn(1280, 640)
+    ad32 = [(rn(4, 640, dt=torch.float32), rn(640, 4, dt=torch.float32)) for _ in range(2)]
+    assert kernels.lora_group(x, wcat, ad32, 0.25) is None
+    wqkv = rn(1920, 640)
+    with pytest.raises(TypeError):
+        kernels.lora_qkv(x, wqkv, ad32 + ad32[:1], 0.25, 10)
+
+    def layer():
+        lin = torch.nn.Linear(640, 640, bias=False, device=gpu, dtype=torch.bfloat16).requires_grad_(False)
+        return SimpleNamespace(linear=lin, enabled=True, rank=4, training_dropout_active=lambda: False, _scale=lambda: 0.25,
+                               lora_down=SimpleNamespace(weight=rn(4, 640, dt=torch.float32)),
+                               lora_up=SimpleNamespace(weight=rn(640, 4, dt=torch.float32)))
+    assert kernels.lora_siblings(x, (layer(), layer())) is None

@@ -36,6 +36,11 @@ print("algorithmic bytes: attn_fwd q+k+v+o =", 4 * B * H * S * D * 2, " lora_fwd
 # (tokens 98304, 640 -> 5120, rank-4 extension + bias) and the 32x32-latent one (tokens 24576, 1280 -> 10240)
 import torch.nn.functional as F  # noqa: E402,F401
 
+# tools/pmc_summarize.py tells the two shapes apart by launch order (3 plain launches each): pin the one-launch 256x256
+# tile, or a split entry (cfg 11-13) of the tile table would double the launches per call and skew the attribution
+from vision_ft_amd import _C  # noqa: E402
+
+_C.check(_C.lib().vft_linear_variant(1), "vft_linear_variant")
 for (M2, N2, K2) in [(98304, 5120, 640), (24576, 10240, 1280)]:
     x2, w2, b2 = bf(M2, K2), bf(N2, K2) * 0.05, bf(N2)
     t2, B2 = bf(M2, 4), bf(N2, 4)
@@ -44,6 +49,7 @@ for (M2, N2, K2) in [(98304, 5120, 640), (24576, 10240, 1280)]:
     torch.cuda.synchronize()
     print(f"lin8 {M2}x{N2}x{K2} algorithmic bytes (x + w + y + ext) =", 2 * (M2 * K2 + N2 * K2 + M2 * N2 + 4 * (M2 + N2)))
     del x2, w2, b2, t2, B2
+_C.check(_C.lib().vft_linear_variant(0), "vft_linear_variant")
 
 # implicit-GEMM convolution (SDXL 320->320 at 128x128, B=16) forward + data gradient
 Bc, Ci, Co, Hc = 24, 320, 320, 128

@@ -642,6 +642,7 @@ class _WgradQueue:
         self.count = 0
         self.max_ne = 0
         self.callback_queued = False
+        self.pending: set[int] = set()  # data_ptr of every gradient tensor with a reduction queued in this pass
 
     @classmethod
     def get(cls, device) -> "_WgradQueue":
@@ -672,7 +673,18 @@ class _WgradQueue:
             with torch.cuda.device(self.device):
                 st = _C.lib().vft_lora_wgrad_reduce_many(_ptr(self.table), self.count, self.max_ne, _stream())
             self.count, self.off, self.max_ne = 0, 0, 0
+            self.pending.clear()
             _C.check(st, "vft_lora_wgrad_reduce_many")
+
+    def claim(self, targets) -> None:
+        """Register the gradient tensors of one layer call.  The single reduce launch gives every table entry its own
+        workgroups and each does `grad += sum`, non-atomically: two entries with the SAME target (one adapter applied twice
+        in a forward pass, or two forward passes summed into one loss) would race and lose a contribution.  A repeated
+        target therefore flushes what is queued first — launches on one stream are ordered, so the sums add up."""
+        ptrs = {g.data_ptr() for pair in targets for g in pair}
+        if self.pending & ptrs:
+            self.flush()
+        self.pending |= ptrs
 
 
 DEFER_WGRAD_REDUCE = os.environ.get("VFT_DEFER_WGRAD", "1") != "0"  # A/B switch
@@ -707,6 +719,7 @@ def _lora_wgrad_into(x2, u, dy2, t, params, r: int, rp: int, s: float):
     du = (ctypes.c_void_p * 3)(*[t_[1].data_ptr() for t_ in targets])
     if inplace and DEFER_WGRAD_REDUCE:
         q = _WgradQueue.get(x2.device)
+        q.claim(targets)
         ws = q.take(max(nbytes // 4, 1))
         if ws is not None:
             with _Timed("lora_wgrad2", 2.0 * M * (K + N)):
@@ -920,6 +933,12 @@ def fused_lora_eligible(weight: torch.Tensor, r: int) -> bool:
             and r <= 16 and weight.is_cuda)
 
 
+def _adapters_ok(weights) -> bool:
+    """Every lora_down / lora_up handed to a grouped entry point is a CUDA bf16 contiguous tensor.  The kernels take raw
+    pointers typed bf16: an fp32 adapter (schema-valid `peft.config.dtype: float32`) would be read as garbage, silently."""
+    return all(w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous() for w in weights)
+
+
 def _bf16_rows(t: torch.Tensor | None) -> torch.Tensor | None:
     if t is None:
         return None
@@ -1045,6 +1064,8 @@ def lora_siblings(x: torch.Tensor, layers) -> list[torch.Tensor] | None:
             s0 = sc
         elif sc != s0:
             return None
+        if not _adapters_ok((m.lora_down.weight, m.lora_up.weight)):
+            return None  # per-layer calls: kernels.lora_linear raises TypeError for what it cannot run
         args += [base.weight, base.bias, m.lora_down.weight, m.lora_up.weight, m.__dict__.get("_vft_pack")]
     _ready(x)
     _require_gpu(x)
@@ -1105,9 +1126,9 @@ def lora_group(x: torch.Tensor, wcat: torch.Tensor, adapters, scale: float, pack
     _require_gpu(x, wcat)
     G = len(adapters)
     r, N = adapters[0][0].shape[0], adapters[0][1].shape[0]
-    if not (FUSED_LORA_GEMM and G in (2, 3) and fused_lora_eligible(wcat, G * r) and N % 64 == 0):
-        return None
     flat = [t_ for pair in adapters for t_ in pair]
+    if not (FUSED_LORA_GEMM and G in (2, 3) and fused_lora_eligible(wcat, G * r) and N % 64 == 0 and _adapters_ok(flat)):
+        return None
     return _LoRAGroupFused.apply(x, wcat, float(scale), pack, G, *flat)
 
 
@@ -1241,6 +1262,7 @@ def lora_qkv(x: torch.Tensor, wqkv: torch.Tensor, adapters, scale: float, heads:
     _ready(x, wqkv)
     _require_gpu(x, wqkv)
     (Aq, Bq), (Ak, Bk), (Av, Bv) = adapters
+    _require_gpu(Aq, Bq, Ak, Bk, Av, Bv)  # fp32 adapters would be read as bf16 by the kernels: fail loudly
     if FUSED_LORA_GEMM and fused_lora_eligible(wqkv, 3 * Aq.shape[0]) and Bq.shape[0] % 64 == 0:
         return _LoRAQKVFused.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads), pack)
     return _LoRAQKV.apply(x, wqkv, Aq, Bq, Ak, Bk, Av, Bv, float(scale), int(heads))
@@ -1554,12 +1576,12 @@ PLAIN_LINEAR_GEMM = os.environ.get("VFT_PLAIN_LINEAR", "1") != "0"  # A/B switch
 
 def linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """nn.Linear calls the projection GEMM takes: FROZEN bf16 weights on the GPU (in_features a multiple of 64, out_features
-    of 8) and enough rows for the 128-row tiles to matter (tiny conditioning MLPs stay on the library).  Trainable weights
+    of 32: the data gradient reduces over out_features and vft_linear_fwd needs K % 32 == 0) and enough rows for the 128-row tiles to matter (tiny conditioning MLPs stay on the library).  Trainable weights
     (full fine-tune) stay on the tuned library GEMMs: measured A/B on one MI355X, SDXL full fine-tune B=16 runs 27.4
     images/s there and 26.1 here — the per-step transposes of 2.6 B weights for the data gradient and the table-tuned
     library solutions outweigh the fused bias / skip epilogue."""
     return (PLAIN_LINEAR_GEMM and not weight.requires_grad and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
-            and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 and x.numel() // x.shape[-1] >= 1024)
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 32 == 0 and x.numel() // x.shape[-1] >= 1024)
 
 
 class _Linear(torch.autograd.Function):

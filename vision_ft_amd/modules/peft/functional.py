@@ -77,8 +77,8 @@ def build_adapter_pack(model: nn.Module):
         bf16_base = type(base) is nn.Linear and kernels.fused_lora_eligible(base.weight, m.rank)
         nf4_base = (hasattr(base, "quant_state") and m.rank in (4, 8, 16) and base.in_features % 64 == 0
                     and base.out_features % 64 == 0)  # the two cases kernels.lora_linear runs on a fused GEMM
-        if ((bf16_base or nf4_base) and m.lora_up.bias is None and m.lora_down.weight.dtype == torch.bfloat16
-                and m.lora_down.weight.device == dev):
+        if ((bf16_base or nf4_base) and m.lora_up.bias is None and m.lora_down.weight.device == dev
+                and kernels._adapters_ok((m.lora_down.weight, m.lora_up.weight))):
             m._vft_pack = pack.add([(m.lora_down.weight, m.lora_up.weight)], kernels._ext_rank(m.rank))
     for mod in model.modules():
         ps = [getattr(mod, n, None) for n in ("to_q", "to_k", "to_v")]

@@ -176,16 +176,26 @@ class Trainer:
         for the log, staging the next batch — overlaps with the collective."""
         self.raw_model.before_backward()
         (loss / self.gradient_accumulation_steps).backward()
+        # `current_step=None` is the reference's own hook signature (backward(loss)): the boundary is then unknown here
+        # and `apply_gradients` runs the exchange itself, un-overlapped but never skipped.
         self._boundary = current_step is not None and current_step % self.gradient_accumulation_steps == 0
+        self._clipped = False
         if self._boundary:
             self.dp.reduce_async()  # skipped on non-boundary micro-steps == the reference's no_sync (:301-308)
-        else:
+        elif current_step is not None:
             self.raw_model.after_backward()
+            self._clipped = True
 
     _boundary = False
+    _clipped = False
 
     def apply_gradients(self, current_step: int) -> None:
         if current_step % self.gradient_accumulation_steps == 0:
+            if not self._boundary and not self._clipped:
+                # a caller on the old backward(loss) / apply_gradients(step) protocol: the exchange was not started in
+                # backward, so do it here — otherwise the ranks would step on local gradients and diverge silently
+                self.dp.reduce_async()
+                self._boundary = True
             if self._boundary:
                 self.dp.wait()
                 self.raw_model.after_backward()  # clipping on the averaged gradient
