@@ -3,8 +3,10 @@
 
   python bench.py --gpus N --steps K --warmup W [--workload sdxl_lora|sdxl_full|aura_lora|lumina_lora] [--batch B]
 
-For N>1 launch one rank per GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from
-the environment); gradients are exchanged with RCCL on a side stream (vision_ft_amd/trainer/dp.py).
+For N>1 either launch one rank per GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the
+environment) or just run `python bench.py --gpus N`: with WORLD_SIZE unset the script starts its own N ranks as CHILD
+processes (torch.distributed.run, rendezvous on 127.0.0.1) before anything touches the GPU and exits with their code.
+Gradients are exchanged with RCCL on a side stream (vision_ft_amd/trainer/dp.py).
 One "step" = noising + denoiser forward + loss + backward + gradient exchange + AdamW update on one
 batch of B synthetic latents per GPU (weak scaling).  Rank 0 prints ONE JSON line.
 """
@@ -34,7 +36,7 @@ F_ALG = {"sdxl_lora": 13.5, "sdxl_full": 20.3, "aura_lora": 88.0, "lumina_lora":
          "sdxl_buckets": 13.5}
 
 
-def build(workload: str, device: torch.device):
+def build(workload: str, device: torch.device, use_rope: bool = False, aura_keys: str = "debug252"):
     from vision_ft_amd.modules.peft import LoRAConfig, PeftTargetConfig, RegexMatch
 
     torch.manual_seed(42)
@@ -47,13 +49,21 @@ def build(workload: str, device: torch.device):
         elif workload.startswith("aura"):
             from vision_ft_amd.models.auraflow import Denoiser, DenoiserConfig
 
-            model = Denoiser(DenoiserConfig())
-            # tests/assets/debug_dataset.yml:17-25 key set of the reference (252 Linears, rank 16)
-            peft = PeftTargetConfig(
-                include_keys=[RegexMatch(regex=r".*\.attn\.w2[qkvo]"), RegexMatch(regex=r".*\.mlp[X]?\."),
-                              RegexMatch(regex=r".*single_layers\.\d+\.attn\.w1[qkvo]")],
-                exclude_keys=["text_encoder", "vae", "t_embedder", "final_linear", RegexMatch(regex=r"\.mod[CX]{1,2}")],
-                config=LoRAConfig(rank=16, alpha=1.0))
+            # learned positional embedding, and a second run with use_rope (rope_dim_sizes [32,112,112])
+            model = Denoiser(DenoiserConfig(use_rope=True, rope_dim_sizes=[32, 112, 112]) if use_rope else DenoiserConfig())
+            if aura_keys == "yaml124":
+                # the reference's shipped configs/auraflow/lora.yml:19-24 (its single_layers regex never matches: 124 Linears)
+                peft = PeftTargetConfig(
+                    include_keys=["attn.w2", RegexMatch(regex=r".*single_layers\.\d+\.w1[qkvo]"), ".mlp.", ".mlpX."],
+                    exclude_keys=["text_encoder", "vae", "t_embedder", "final_linear", ".mod"],
+                    config=LoRAConfig(rank=16, alpha=1.0))
+            else:
+                # tests/assets/debug_dataset.yml:17-25 key set of the reference (252 Linears, rank 16)
+                peft = PeftTargetConfig(
+                    include_keys=[RegexMatch(regex=r".*\.attn\.w2[qkvo]"), RegexMatch(regex=r".*\.mlp[X]?\."),
+                                  RegexMatch(regex=r".*single_layers\.\d+\.attn\.w1[qkvo]")],
+                    exclude_keys=["text_encoder", "vae", "t_embedder", "final_linear", RegexMatch(regex=r"\.mod[CX]{1,2}")],
+                    config=LoRAConfig(rank=16, alpha=1.0))
             with torch.no_grad():  # the reference zero-inits these; re-init so outputs are non-trivial
                 for n, p in model.named_parameters():
                     if ".mod" in n or n in ("final_linear.weight", "cond_seq_linear.weight"):
@@ -84,7 +94,8 @@ def build(workload: str, device: torch.device):
     return model
 
 
-def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int, int] = (1024, 1024)):
+def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int, int] = (1024, 1024),
+              drawn_lengths: bool = False):
     from vision_ft_amd.modules.loss import diffusion as LD
     from vision_ft_amd.modules.loss import flow_match as LF
     from vision_ft_amd.modules.timestep.sampling import sigmoid_randn, uniform_rand, uniform_randint
@@ -112,14 +123,21 @@ def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int
             return LF.loss_with_predicted_velocity(lat.float(), noise.float(), pred.float())
     else:
         lat, cap = rn(batch, 16, 128, 128), rn(batch, 256, 2304)
-        mask = torch.ones(batch, 256, dtype=torch.bool, device=device)
+        full = torch.ones(batch, 256, dtype=torch.bool, device=device)
+        draw = torch.Generator().manual_seed(1000 + seed)  # host side: a data loader knows the lengths before the copy
+        pos = torch.arange(256, device=device)[None, :]
 
         def fwd():
             t = uniform_rand(lat.shape, device)
             noisy, noise = LF.prepare_noised_latents(lat, (1 - t).to(lat.dtype))
             # caption lengths as host integers (a data loader knows them before the batch goes to the device): without them the
             # model reads them back from the mask — the step's only host synchronisation, which also rules out graph replay
-            out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask, caption_lengths=[256] * batch,
+            if drawn_lengths:  # mask lengths U{32..256}, seeded; a new ragged layout every step
+                lens = torch.randint(32, 257, (batch,), generator=draw).tolist()
+                mask = pos < torch.tensor(lens, device=device)[:, None]
+            else:
+                lens, mask = [256] * batch, full
+            out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask, caption_lengths=lens,
                               padded_output=True)
             pred = -out
             return LF.loss_with_predicted_velocity(lat.float(), noise.float(), pred.float())
@@ -157,10 +175,10 @@ def cpu_baseline(threads: int) -> dict:
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     linears = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.Linear)]
     targets = sorted(set(get_target_keys(["attn1", "attn2", ".ff."], [], [n for n, _ in m.named_modules()])) & set(linears))
-    r = time_sdxl_lora_step(shapes, targets, threads=threads, warmup=2, steps=5)
+    r = time_sdxl_lora_step(shapes, targets, threads=threads, warmup=1, steps=2)
     return {"value": round(r["images_per_s"], 5), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"oracle restatement of BASELINE config 1 (SDXL UNet LoRA r4 x{len(targets)} Linears, B=1, 512^2, AdamW, "
-                      f"autocast cpu bf16) on all {threads} physical host cores: 2 warm-up + 5 timed steps, {r['s_per_step']:.2f} s/step"}
+                      f"autocast cpu bf16) on all {threads} physical host cores: 1 warm-up + 2 timed steps (a bounded sample), {r['s_per_step']:.2f} s/step"}
 
 
 def per_call_roofline(prof: dict) -> dict:
@@ -172,7 +190,7 @@ def per_call_roofline(prof: dict) -> dict:
         if v["ms"] <= 0:
             continue
         rate = v["work"] / (v["ms"] * 1e-3)
-        mfma = k.startswith(("attn_", "conv3x3", "gemm_", "linear_"))
+        mfma = k.startswith(("attn_", "conv3x3", "gemm_", "linear_", "lib_gemm"))
         if mfma:
             out[k] = {"bound": "mfma", "achieved": round(rate / 1e12, 1), "unit": "TFLOP/s", "frac": round(rate / 1e12 / PEAK_BF16_MFMA_TFLOPS, 3)}
         else:
@@ -187,7 +205,10 @@ FAMILIES = {
     "attention_fwd": (("attn_fwd",), "attn_fwd_kernel", "mfma"),
     "conv3x3": (("conv3x3_fwd", "conv3x3_dgrad"), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
     "weight_grad": (("linear_wgrad", "conv3x3_wgrad"), "wg8_kernel (vft_linear_wgrad / vft_conv3x3_wgrad: weight gradients of trainable projections and 3x3 convolutions)", "mfma"),
-    "gemm_nf4": (("gemm_nf4",), "linear_kernel NF4 modes (vft_linear_nf4)", "mfma"),
+    "gemm_nf4": (("gemm_nf4",), "NF4 dequantising projection GEMM (vft_linear_nf4)", "mfma"),
+    # NOT ours: the library GEMMs that remain (full fine-tune: trainable projections), timed like the rest so that the
+    # dominant kernel is named honestly when it is theirs
+    "library_gemm": (("lib_gemm",), "hipBLASLt Cijk_* (torch F.linear / matmul of trainable weights: forward, data gradient, large weight gradients)", "mfma"),
     "lora_rank": (("lora_",), "lora_rows_kernel / lora_wgrad kernels", "hbm"),
     "norms_activations": (("norm_", "groupnorm_", "geglu_", "swiglu_", "gate_residual", "qk_norm_rope", "colsum"), "norm / GroupNorm / GEGLU / SwiGLU / column-sum kernels", "hbm"),
 }
@@ -230,6 +251,24 @@ def pmc_traffic(family: str):
     return None, None
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process and return
+    its exit code.  Called before this process has made any GPU call (never exec from a process that has, and the children
+    initialise the GPU themselves)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL over dmabuf IPC (the host driver has no legacy IPC)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,18 +278,36 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single", action="store_true", help="time only --workload (a default run adds an AuraFlow-LoRA leg)")
+    ap.add_argument("--nf4-cache", action="store_true", help="lumina_qlora: compute on a dequantised bf16 copy (labelled option)")
+    ap.add_argument("--drawn-lengths", action="store_true", help="lumina_*: caption lengths U{32..256} per step (eager)")
+    ap.add_argument("--use-rope", action="store_true", help="aura_lora: use_rope=True, rope_dim_sizes [32,112,112]")
+    ap.add_argument("--aura-keys", default="debug252", choices=["debug252", "yaml124"], help="aura_lora: LoRA target key set")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-gemm-table", action="store_true", help="library GEMMs use their default heuristic, not the committed table")
     ap.add_argument("--tune-gemms", action="store_true", help="time library GEMM solutions for missing shapes and update the table")
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    # ---- N > 1 without a launcher: start the ranks ourselves, as child processes, BEFORE any GPU call (this process never
+    #      touches the GPU; it only relays the children's exit code — rank 0's JSON line goes straight to our stdout)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.launch_selftest:
+        # host-only rehearsal of the launch path (tests/test_host_logic.py, no GPU): process group, barrier, the MAX
+        # reduction the timing uses, one JSON line from rank 0
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"selftest": "launch", "n_gpus": world, "max_over_ranks": float(t.item())}))
+        dist.destroy_process_group()
+        return
     # (test hooks: VFT_FORCE_DEVICE / VFT_DIST_BACKEND=gloo let two ranks share one GPU to rehearse the N>1 path)
     device = torch.device("cuda", int(os.environ.get("VFT_FORCE_DEVICE", local)))
     torch.cuda.set_device(device)
@@ -272,15 +329,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_workload(workload: str, batch: int, steps: int, warmup: int) -> dict:
+    def run_workload(workload: str, batch: int, steps: int, warmup: int, nf4_cache: bool = False, drawn_lengths: bool = False,
+                     use_rope: bool = False, aura_keys: str = "debug252") -> dict:
         """Build, warm up, time `steps` steps (barrier + synchronize on both sides, max over ranks), then an eager pass with
-        HIP events around every hand-written launch.  Returns the result dict of this workload."""
-        model = build(workload, device)
+        HIP events around every hand-written launch.  Returns the result dict of this workload.
+        nf4_cache: Lumina2-QLoRA computes on a dequantised bf16 copy (an MI355X memory-for-speed option) instead of the
+        fused in-kernel dequantisation BASELINE config 4 names; drawn_lengths: caption lengths U{32..256} per step (eager:
+        every step has a new ragged layout); use_rope / aura_keys: the AuraFlow variants of SURVEY §8d config 3."""
+        from vision_ft_amd.modules.quant import nf4 as _nf4
+
+        _nf4.NF4_COMPUTE_CACHE = bool(nf4_cache)
+        model = build(workload, device, use_rope=use_rope, aura_keys=aura_keys)
         params = [p for p in model.parameters() if p.requires_grad]
         dp = DataParallelGrads(params)
-        use_graph = not args.no_graph
+        use_graph = not args.no_graph and not drawn_lengths
         opt = torch.optim.AdamW(params, lr=1e-3, fused=True, capturable=use_graph)
-        fwd = make_step(workload, model, device, batch, seed=42 + rank)
+        fwd = make_step(workload, model, device, batch, seed=42 + rank, drawn_lengths=drawn_lengths)
 
         def eager_step():
             loss = fwd()
@@ -373,8 +437,9 @@ def main():
             ms_per_step = 1e3 * elapsed / steps
             fam = family_table(prof, prof_steps)
             ours_ms = sum(v["ms_per_step"] for v in fam.values())
-            # the kernel with the largest share of the step among the hand-written ones (measured, not assumed)
+            # the kernel family with the largest share of the step — ours or the library's (measured, not assumed)
             dom = max(fam, key=lambda k: fam[k]["ms_per_step"]) if fam else None
+            ours_ms = sum(v["ms_per_step"] for k, v in fam.items() if k != "library_gemm")
             traffic, traffic_note = pmc_traffic(dom) if dom else (None, None)
             roofline = {"bound": fam[dom]["bound"], "kernel": fam[dom]["kernel"], "family": dom, "achieved": fam[dom]["achieved"],
                         "peak": PEAK_BF16_MFMA_TFLOPS if fam[dom]["bound"] == "mfma" else PEAK_HBM_GBS, "unit": fam[dom]["unit"],
@@ -384,9 +449,9 @@ def main():
             roofline.update({
                 "families": fam,
                 "hand_written_ms_per_step": round(ours_ms, 1),
-                # what is NOT one of our C-ABI launches in the eager pass: library GEMMs / MIOpen convolutions that remain
-                # (time-embedding MLPs, 4-channel stem/head, stride-2 and 1x1 convolutions, weight gradients of a full
-                # fine-tune), ATen elementwise, the optimizer
+                # what is NOT one of our C-ABI launches in the eager pass: library GEMMs (the timed ones are also the
+                # "library_gemm" family above) / MIOpen convolutions that remain (time-embedding MLPs, 4-channel stem / head,
+                # stride-2 convolutions), ATen elementwise, the optimizer
                 "library_and_aten_ms_per_step": round(max(ms_per_step - ours_ms, 0.0), 1),
                 "eager_pass_ms_per_step": None if eager_ms is None else round(eager_ms, 1),
                 "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items()},
@@ -402,9 +467,13 @@ def main():
                            "peak_mem_gib": round(peak_timed, 1), "algorithmic_tflop_per_image": F_ALG[workload],
                            **({"buckets": bucket_note} if bucket_note else {}),
                            **({"base_weights": "NF4 (blocksize 64, double-quantised absmax): " + (
-                               "module state / checkpoint format; compute on a dequantised bf16 cache (VFT_NF4_CACHE=1, default)"
-                               if _nf4_cache_on() else "the only copy in HBM, dequantised inside the GEMM kernel (VFT_NF4_CACHE=0)")}
-                              if workload == "lumina_qlora" else {})},
+                               "module state / checkpoint format; compute on a dequantised bf16 cache (VFT_NF4_CACHE=1: NOT the "
+                               "config as BASELINE states it — a labelled memory-for-speed option)"
+                               if _nf4_cache_on() else "the only copy in HBM, dequantised inside the GEMM kernel (VFT_NF4_CACHE=0, default)"),
+                               "caption_lengths": "U{32..256} drawn per step (seeded), eager launches" if drawn_lengths else "256 (fixed)"}
+                              if workload.startswith("lumina") else {}),
+                           **({"use_rope": use_rope, "lora_key_set": "configs/auraflow/lora.yml (124 Linears)" if aura_keys == "yaml124"
+                               else "tests/assets/debug_dataset.yml (252 Linears)"} if workload.startswith("aura") else {})},
                 "roofline": roofline,
             }
         # free everything before the next leg
@@ -416,16 +485,25 @@ def main():
         torch.cuda.reset_peak_memory_stats(device)
         return res
 
-    main_res = run_workload(args.workload, args.batch or default_batch[args.workload], args.steps, args.warmup)
+    main_res = run_workload(args.workload, args.batch or default_batch[args.workload], args.steps, args.warmup,
+                            nf4_cache=args.nf4_cache, drawn_lengths=args.drawn_lengths, use_rope=args.use_rope, aura_keys=args.aura_keys)
     # The metric names two models ("SDXL-LoRA, AuraFlow-MMDiT"): a default run also times AuraFlow-LoRA (BASELINE config 3,
     # rank 16, 252 Linears) with its own roofline, reported under "workloads".  `value` stays the named workload's.
     legs = {}
     if args.workload == "sdxl_lora" and not args.single:
-        legs["aura_lora"] = run_workload("aura_lora", default_batch["aura_lora"], max(3, min(args.steps, 5)), 2)
+        short = max(3, min(args.steps, 5))
+        legs["aura_lora"] = run_workload("aura_lora", default_batch["aura_lora"], short, 2)
         if world == 1:  # BASELINE configs[1] (SDXL full fine-tune, 1 GPU): a third, single-GPU leg of the default run
-            legs["sdxl_full"] = run_workload("sdxl_full", default_batch["sdxl_full"], max(3, min(args.steps, 5)), 2)
-            # BASELINE configs[3] (Lumina-Image-2.0 NextDiT QLoRA: NF4 base + bf16 LoRA)
-            legs["lumina_qlora"] = run_workload("lumina_qlora", default_batch["lumina_qlora"], max(3, min(args.steps, 5)), 2)
+            legs["sdxl_full"] = run_workload("sdxl_full", default_batch["sdxl_full"], short, 2)
+            # BASELINE configs[3] (Lumina-Image-2.0 NextDiT QLoRA: NF4 base + bf16 LoRA) AS WRITTEN: the 4-bit weights are the
+            # only copy in HBM and are dequantised inside the GEMM kernel
+            legs["lumina_qlora"] = run_workload("lumina_qlora", default_batch["lumina_qlora"], short, 2)
+            # ... and its variants, labelled: caption lengths drawn U{32..256}, and the bf16 compute cache
+            legs["lumina_qlora_drawn_lengths"] = run_workload("lumina_qlora", default_batch["lumina_qlora"], 3, 1, drawn_lengths=True)
+            legs["lumina_qlora_bf16_cache"] = run_workload("lumina_qlora", default_batch["lumina_qlora"], 3, 2, nf4_cache=True)
+            # SURVEY §8d config 3, the other two AuraFlow runs: use_rope=True, and the shipped YAML's 124-Linear key set
+            legs["aura_lora_rope"] = run_workload("aura_lora", default_batch["aura_lora"], 3, 2, use_rope=True)
+            legs["aura_lora_yaml124"] = run_workload("aura_lora", default_batch["aura_lora"], 3, 2, aura_keys="yaml124")
 
     if rank == 0:
         out = {

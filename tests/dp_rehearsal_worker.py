@@ -50,3 +50,20 @@ def run_rank(rank: int, world: int, port: int, out_dir: str, hip_graph: bool) ->
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def run_self_launched_bench(out_path: str) -> None:
+    """Body of tests/test_dp_gpu.py::test_bench_gpus_2_self_launch: runs in a child of the clean fork server (this process
+    has never touched the GPU), so starting bench.py — which starts its own two ranks — is an ordinary child process."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VFT_FORCE_DEVICE="0", VFT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single", "--batch", "1", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-gemm-table"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    with open(out_path, "w") as f:
+        json.dump({"rc": r.returncode, "stdout": r.stdout[-20000:], "stderr": r.stderr[-4000:]}, f)

@@ -94,3 +94,27 @@ def test_two_ranks_on_one_gpu_match_the_mean_gradient_run(gpu, tmp_path):
         assert len(graph[r]["losses"]) == 3
         assert abs(graph[r]["losses"][0] - eager[r]["losses"][0]) < 5e-3 * abs(eager[r]["losses"][0])
         assert all(torch.isfinite(torch.tensor(graph[r]["losses"])))
+
+
+def test_bench_gpus_2_self_launch(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) starts its two ranks itself and prints ONE JSON line with
+    n_gpus = 2 and the whole-job rate.  Rehearsed on the one GPU (both ranks on cuda:0, gloo transport): everything of the
+    driver's N > 1 command line except RCCL itself."""
+    import json
+
+    from .dp_rehearsal_worker import run_self_launched_bench
+
+    out = tmp_path / "bench2.json"
+    ctx = multiprocessing.get_context("forkserver")
+    p = ctx.Process(target=run_self_launched_bench, args=(str(out),))
+    p.start()
+    p.join(timeout=1000)
+    assert p.exitcode == 0
+    res = json.loads(out.read_text())
+    assert res["rc"] == 0, res["stderr"]
+    lines = [ln for ln in res["stdout"].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res["stdout"][-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["global_batch"] == 2 and line["value"] > 0
+    assert abs(line["value"] - 2 * 1 / (line["ms_per_step"] * 1e-3)) < 0.02 * line["value"]

@@ -366,3 +366,48 @@ def test_bench_picks_the_dominant_kernel_family_from_the_profile():
     assert fam["norms_activations"]["bound"] == "hbm" and fam["norms_activations"]["ms_per_step"] == 19.0
     assert fam["lora_rank"]["unit"] == "GB/s"
     assert bench.physical_cores() >= 1
+
+
+def test_bench_names_the_library_gemm_when_it_dominates():
+    """Full fine-tune: when the library's GEMMs (timed like our launches) are the largest family, the roofline object must
+    say so (the sdxl_full line named wg8 while hipBLASLt had the larger share)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("vft_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = {"linear_wgrad": {"launches": 900, "work": 2 * 4.0e13, "ms": 2 * 57.0},
+            "conv3x3_wgrad": {"launches": 72, "work": 2 * 3.9e13, "ms": 2 * 52.0},
+            "lib_gemm_fwd": {"launches": 646, "work": 2 * 1.0e14, "ms": 2 * 80.0},
+            "lib_gemm_dgrad": {"launches": 646, "work": 2 * 1.0e14, "ms": 2 * 85.0},
+            "lib_gemm_wgrad": {"launches": 86, "work": 2 * 6.0e13, "ms": 2 * 70.0}}
+    fam = bench.family_table(prof, 2)
+    assert max(fam, key=lambda k: fam[k]["ms_per_step"]) == "library_gemm"
+    assert fam["library_gemm"]["ms_per_step"] == 235.0 and "hipBLASLt" in fam["library_gemm"]["kernel"]
+    assert bench.per_call_roofline(prof)["lib_gemm_fwd"]["bound"] == "mfma"
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start two ranks as child processes (torch.distributed.run on
+    127.0.0.1) and print rank 0's single JSON line (a plain `--gpus N` exited with an instruction).  Host-only
+    rehearsal of the launch path: gloo, no GPU call."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"selftest": "launch", "n_gpus": 2, "max_over_ranks": 2.0}
+    # a rank count that contradicts the launcher's is refused, not silently accepted
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env2, cwd=root,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=3" in (r2.stderr + r2.stdout)

@@ -1668,7 +1668,8 @@ class _LinearTrained(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.params = (weight, bias)
-        return F.linear(x, weight, bias)
+        with _Timed("lib_gemm_fwd", 2.0 * (x.numel() // x.shape[-1]) * weight.shape[0] * weight.shape[1]):
+            return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1676,8 +1677,10 @@ class _LinearTrained(torch.autograd.Function):
         wparam, bparam = ctx.params
         dy2, x2 = _bf16_rows(dy), _bf16_rows(x)
         dx = dw = db = None
+        flops = 2.0 * dy2.shape[0] * weight.shape[0] * weight.shape[1]
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ weight).view(x.shape)
+            with _Timed("lib_gemm_dgrad", flops):
+                dx = (dy2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             g = _grad_target(wparam)
             if _wgrad_on_kernel(dy2.shape[0], weight.shape[0], weight.shape[1]) and linear_wgrad_eligible(dy2, x2):
@@ -1687,7 +1690,8 @@ class _LinearTrained(torch.autograd.Function):
                     else:
                         dw = linear_wgrad(dy2, x2)
             else:
-                dw = dy2.t() @ x2
+                with _Timed("lib_gemm_wgrad", flops):
+                    dw = dy2.t() @ x2
         if bparam is not None and ctx.needs_input_grad[2]:
             db = colsum(dy2, bparam)
         return dx, dw, db

@@ -26,14 +26,15 @@ import torch.nn as nn
 
 from ... import kernels
 
-# MI355X option: keep a dequantised bf16 copy of every NF4 weight for COMPUTE (the packed codes stay the module's state and
-# the checkpoint format).  With 288 GB per GPU the copy (2 + 2 bytes per parameter with the transposed one for the data
-# gradient: ~10 GB for Lumina2) is affordable, the adapted layer then runs on the bf16 projection GEMM (lin8: 1.2-1.3 PF)
-# instead of the dequantising first-generation kernel (0.65-0.86 PF), and the GEMM's input is bit-identical (the same
-# code x absmax products rounded to bf16).  Measured on one MI355X (Lumina2-QLoRA, B=4): 13.6 images/s with the cache,
-# 11.2 with the in-GEMM dequantisation — so it is ON by default; VFT_NF4_CACHE=0 keeps the 4-bit weights the only copy in
-# HBM (the dequantising GEMM, vft_linear_nf4).
-NF4_COMPUTE_CACHE = os.environ.get("VFT_NF4_CACHE", "1") != "0"
+# Default: the packed 4-bit codes are the ONLY copy of the weight in HBM and are dequantised inside the projection GEMM
+# (vft_linear_nf4) — BASELINE config 4 as written ("fuses NF4->bf16 dequant into the down/up matmul in-kernel",
+# reference: src/modules/quant/bnb.py:37-129 -> bnb.matmul_4bit).
+# MI355X option VFT_NF4_CACHE=1: additionally keep a dequantised bf16 copy of every NF4 weight for COMPUTE (the packed codes
+# stay the module's state and the checkpoint format).  With 288 GB per GPU the copy (2 + 2 bytes per parameter with the
+# transposed one for the data gradient: ~10 GB for Lumina2) is affordable and the adapted layer then runs on the bf16
+# projection GEMM with a bit-identical GEMM input (the same code x absmax products rounded to bf16) — a memory-for-speed
+# trade that bench.py reports as its own, labelled leg, never as config 4.
+NF4_COMPUTE_CACHE = os.environ.get("VFT_NF4_CACHE", "0") != "0"
 
 _SUFFIXES = ("absmax", "quant_map", "nested_absmax", "nested_quant_map", "quant_state.bitsandbytes__nf4")
 
