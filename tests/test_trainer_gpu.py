@@ -135,6 +135,66 @@ def test_real_image_front_half_trains(gpu, tmp_path):
     assert {s[4][2:] for s in seen} == {(256, 256), (320, 192)}  # (h, w) of the 256x256 and 192x320 buckets
 
 
+def test_latent_cache_trains(gpu, tmp_path):
+    """SURVEY §8 f3, latent-cache route: the encoders run once (dataset/latent_cache.py, stand-ins here), the Trainer then
+    reads latents, text conditions and the recorded size conditions from the cache — no encoder attached — and replays
+    its HIP graphs per bucket shape."""
+    import sys
+
+    import numpy as np
+    from PIL import Image
+
+    sys.path.insert(0, ".")
+    from train.sdxl.text_to_image import SDXLForTextToImageTraining
+    from vision_ft_amd.dataset.latent_cache import CachedLatentDatasetConfig, LatentCacheWriter
+    from vision_ft_amd.dataset.text_to_image import TextToImageDatasetConfig
+    from vision_ft_amd.trainer.common import Trainer
+
+    folder, cache = tmp_path / "images", tmp_path / "cache"
+    folder.mkdir()
+    rng = np.random.default_rng(0)
+    for i, (w, h) in enumerate([(300, 270), (330, 262), (200, 340), (210, 350), (512, 512)]):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(folder / f"{i}.png")
+        (folder / f"{i}.txt").write_text(f"a picture number {i}")
+
+    def image_encoder(px):
+        lat = torch.nn.functional.avg_pool2d(px.float(), 8)
+        return torch.cat([lat, lat[:, :1]], dim=1)
+
+    def prompt_encoder(captions):
+        g = torch.Generator().manual_seed(sum(map(len, captions)))
+        return {"ehs": torch.randn(len(captions), 77, 64, generator=g), "pooled": torch.randn(len(captions), 1280, generator=g)}
+
+    src = TextToImageDatasetConfig(folder=str(folder), batch_size=2, bucket_base_size=256, step=64, min_size=128, num_workers=0)
+    index = LatentCacheWriter(str(cache), image_encoder, prompt_encoder, crops_per_image=2).build(src)
+    assert len({e["file"] for e in index["entries"]}) == 5
+    cfg = _config(tmp_path, True)
+    cfg.dataset = {"cache_folder": str(cache), "batch_size": 2, "num_workers": 0}
+    trainer = Trainer(cfg)
+    trainer.register_train_dataset_class(CachedLatentDatasetConfig)
+    trainer.register_model_class(SDXLForTextToImageTraining)
+    task = trainer.model
+    assert task.image_encoder is None and task.prompt_encoder is None
+    seen = []
+    stage = task._stage_cached_batch
+
+    def spy(batch):
+        key = stage(batch)
+        lat, cond = task._static[key]
+        seen.append((tuple(lat.shape), cond["original_size"].tolist(), cond["target_size"].tolist(), cond["crop"].tolist()))
+        return key
+
+    task._stage_cached_batch = spy
+    trainer.train()
+    assert len(trainer.losses) == 2 * 3 and all(torch.isfinite(torch.tensor(trainer.losses)))
+    recorded = {(tuple(e["original_size"]), tuple(e["crop"])) for e in index["entries"]}
+    for lat_shape, orig, target, crop in seen:
+        assert lat_shape[0] == 2 and lat_shape[1] == 4
+        for o, t, c in zip(orig, target, crop):
+            assert t == [lat_shape[2] * 8, lat_shape[3] * 8] and (tuple(o), tuple(c)) in recorded
+    assert {s[0][2:] for s in seen} == {(32, 32), (40, 24)}  # latents of the 256x256 and 192x320 (w x h) buckets
+
+
 @pytest.mark.parametrize("accum", [1, 2])
 def test_graph_replay_takes_the_same_steps_as_eager(gpu, tmp_path, accum):
     """HIP-graph mode is an execution detail: same seeds -> the same per-step losses as the eager loop, with an

@@ -53,15 +53,16 @@ class ObjectCoverResize:
         return out.squeeze(0).to(img.dtype)
 
 
-def random_crop_params(image: torch.Tensor, output_size: tuple[int, int]) -> tuple[int, int, int, int]:
-    """v2.RandomCrop.get_params: (top, left, height, width); two `torch.randint` draws from the global generator, top
-    first — the order matters for seeded reproducibility."""
+def random_crop_params(image: torch.Tensor, output_size: tuple[int, int],
+                       generator: torch.Generator | None = None) -> tuple[int, int, int, int]:
+    """v2.RandomCrop.get_params: (top, left, height, width); two `torch.randint` draws from the global generator (or
+    `generator`: the latent cache seeds one per file), top first — the order matters for seeded reproducibility."""
     h, w = image.shape[-2:]
     th, tw = output_size
     if h < th or w < tw:
         raise ValueError(f"Required crop size {(th, tw)} is larger than input image size {(h, w)}")
     if w == tw and h == th:
         return 0, 0, h, w
-    top = int(torch.randint(0, h - th + 1, size=(1,)).item())
-    left = int(torch.randint(0, w - tw + 1, size=(1,)).item())
+    top = int(torch.randint(0, h - th + 1, size=(1,), generator=generator).item())
+    left = int(torch.randint(0, w - tw + 1, size=(1,), generator=generator).item())
     return top, left, th, tw

@@ -92,8 +92,21 @@ class DenoiserTask(ModelForTraining):
         images = batch["image"].to(dev, non_blocking=True)
         lat = self.image_encoder(images)
         cond = self.conditions_from_batch(batch, self.prompt_encoder(list(batch["caption"])))
-        cond = {k: v.to(dev) for k, v in cond.items()}
-        key = ("image", tuple(lat.shape), tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
+        return self._stage_static("image", lat, {k: v.to(dev) for k, v in cond.items()})
+
+    @torch.no_grad()
+    def _stage_cached_batch(self, batch: dict) -> tuple:
+        """A batch of `CachedLatentDatasetConfig` (dataset/latent_cache.py): latents and text conditions were encoded once,
+        off this box; the size conditions are the ones the dataset recorded with each crop."""
+        from ..dataset.latent_cache import split_text_conditions
+
+        dev = self.accelerator.device
+        lat = batch["latents"].to(dev, str_to_dtype(self.model_config.dtype), non_blocking=True)
+        cond = self.conditions_from_batch(batch, split_text_conditions(batch))
+        return self._stage_static("cached", lat, {k: v.to(dev) for k, v in cond.items()})
+
+    def _stage_static(self, tag: str, lat: torch.Tensor, cond: dict[str, torch.Tensor]) -> tuple:
+        key = (tag, tuple(lat.shape), tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
         if key not in self._static:
             self._static[key] = (lat.clone(), {k: v.clone() for k, v in cond.items()})
         else:
@@ -108,6 +121,8 @@ class DenoiserTask(ModelForTraining):
         """Materialise the batch on the device into per-shape static tensors; returns the graph key."""
         if "image" in batch:
             return self._stage_image_batch(batch)
+        if "latents" in batch:
+            return self._stage_cached_batch(batch)
         w, h, seeds = batch["width"], batch["height"], batch["seeds"]
         w, h = (int(w[0]) if isinstance(w, (list, tuple)) else int(w)), (int(h[0]) if isinstance(h, (list, tuple)) else int(h))
         key = (w, h, len(seeds))
