@@ -159,3 +159,62 @@ def test_weight_gradient_kernels_at_full_size(gpu):
     corner = kernels.linear_wgrad(gy2, shifted.permute(0, 2, 3, 1).reshape(-1, C))
     assert rel_err(dw[:, 0, 2, :], corner.float()) < 4e-3
     assert torch.equal(dw, kernels.conv3x3_wgrad(gy, x).view(C, 3, 3, C))
+
+
+@pytest.mark.parametrize("hw", [(192, 80), (80, 192)])  # latents of the 640x1536 (w x h) bucket and its transpose
+def test_non_square_bucket_at_full_size(gpu, hw):
+    """BASELINE config 5's extreme buckets at full size (the round-2 full-size runs were square only): the 3x3 convolution
+    (centre tap = per-pixel linear, off-centre tap = shift with zero padding at BOTH unequal borders, data gradient),
+    GroupNorm statistics and self-attention over H*W = 15 360 tokens (rows sum to one, keys are a set, backward linear in
+    dO) on the rectangular latent."""
+    from vision_ft_amd import kernels
+
+    H, W = hw
+    B, C = 8, 320
+    x = _bf(gpu, B, C, H, W, seed=40).contiguous(memory_format=torch.channels_last)
+    w1 = _bf(gpu, C, C, sc=C**-0.5, seed=41)
+    b = _bf(gpu, C, sc=0.1, seed=42)
+    w = torch.zeros(C, C, 3, 3, device=gpu, dtype=torch.bfloat16)
+    w[:, :, 1, 1] = w1
+    w = w.contiguous(memory_format=torch.channels_last)
+    y = kernels.conv3x3(x, w, b)
+    assert y.shape == (B, C, H, W)
+    assert rel_err(y, F.linear(x.permute(0, 2, 3, 1), w1, b).permute(0, 3, 1, 2).float()) < 4e-3
+    for (kh, kw) in ((0, 2), (2, 0), (1, 0), (2, 1)):  # y[oh, ow] = x[oh + kh - 1, ow + kw - 1], zeros outside
+        ws = torch.zeros(C, C, 3, 3, device=gpu, dtype=torch.bfloat16)
+        ws[:, :, kh, kw] = torch.eye(C, device=gpu, dtype=torch.bfloat16)
+        ys = kernels.conv3x3(x, ws.contiguous(memory_format=torch.channels_last), None)
+        shifted = torch.zeros_like(x)
+        dh, dw = kh - 1, kw - 1
+        shifted[:, :, max(0, -dh):H - max(0, dh), max(0, -dw):W - max(0, dw)] = x[:, :, max(0, dh):H - max(0, -dh), max(0, dw):W - max(0, -dw)]
+        assert torch.equal(ys, shifted), (kh, kw)
+    xg = x.detach().clone().requires_grad_(True)
+    gy = _bf(gpu, B, C, H, W, seed=43).contiguous(memory_format=torch.channels_last)
+    kernels.conv3x3(xg, w, b).backward(gy)
+    assert rel_err(xg.grad, (gy.permute(0, 2, 3, 1).float() @ w1.float()).permute(0, 3, 1, 2)) < 4e-3
+    # weight gradient of the centre tap = the linear weight gradient over all pixels
+    dw_ = kernels.conv3x3_wgrad(gy, x)
+    ref = gy.permute(0, 2, 3, 1).reshape(-1, C).float().t() @ x.permute(0, 2, 3, 1).reshape(-1, C).float()
+    assert dw_.shape == (C, 9 * C)  # rows = [tap][Cin]: the centre tap is block 4
+    assert rel_err(dw_[:, 4 * C:5 * C].float(), ref) < 6e-3
+
+    xs = (x.float() * 3 + 1.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    yn = kernels.group_norm(xs, None, None, 32, 1e-5, silu=False)
+    yg = yn.float().reshape(B, 32, C // 32, H * W).permute(0, 1, 3, 2).reshape(B, 32, -1)
+    assert yg.mean(-1).abs().max() < 1e-2 and (yg.var(-1) - 1).abs().max() < 2e-2
+
+    Bh, Hh, S, D = 2, 5, H * W, 64  # SDXL's first attention level works on the 2x-downsampled latent; full H*W is the harder case
+    q, k, v = (_bf(gpu, Bh, Hh, S, D, seed=s).requires_grad_(True) for s in (44, 45, 46))
+    ones = torch.ones(Bh, Hh, S, D, device=gpu, dtype=torch.bfloat16)
+    assert (kernels.flash_attention(q, k, ones).float() - 1).abs().max() < 2e-2
+    o = kernels.flash_attention(q, k, v)
+    perm = torch.randperm(S, device=gpu)
+    assert rel_err(kernels.flash_attention(q, k[:, :, perm], v[:, :, perm]), o.float()) < 1e-2
+    g1, g2 = _bf(gpu, Bh, Hh, S, D, seed=47), _bf(gpu, Bh, Hh, S, D, seed=48)
+    ga = torch.autograd.grad(o, (q, k, v), g1, retain_graph=True)
+    gb = torch.autograd.grad(o, (q, k, v), g2, retain_graph=True)
+    gab = torch.autograd.grad(o, (q, k, v), (g1.float() + g2.float()).to(torch.bfloat16), retain_graph=True)
+    for a_, b_, c_ in zip(ga, gb, gab):
+        assert rel_err(c_, a_.float() + b_.float()) < 1.5e-2
+    (dv,) = torch.autograd.grad(o, (v,), torch.ones_like(o))
+    assert rel_err(dv.float().sum(2), torch.full((Bh, Hh, D), float(S), device=gpu)) < 5e-3

@@ -234,6 +234,96 @@ def test_qlora_tiny_lumina_step(gpu, nf4_mode):
     assert all(p.grad is None for n, p in qmodel.named_parameters() if "lora_" not in n)
 
 
+def test_qlora_lumina_matches_the_oracle_on_dequantised_weights(gpu, nf4_mode):
+    """BASELINE config 4 against the ORACLE (the only model-level config-4 check compared the product with
+    itself at 0.15): the target Linears are quantised by oracle/nf4.py (numpy restatement of the bitsandbytes layout) and
+    loaded into the product through the checkpoint-sniffing path; oracle/lumina2.py runs on the oracle's own dequantised
+    weights (+ the same LoRA adapters), the GPU model on the 4-bit weights — in both compute modes.  Output at the model
+    tolerance (rel-L2 2e-2), loss and three AdamW LoRA steps' losses at rtol 5e-3: the tolerances of the bf16 model tests."""
+    from oracle import fixture_weights as fw
+    from oracle import lumina2 as olum
+    from oracle import ops
+    from vision_ft_amd.models.lumina2 import Denoiser, DenoiserConfig
+    from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity
+    from vision_ft_amd.modules.peft import LoRAConfig, PeftTargetConfig
+    from vision_ft_amd.modules.quant import NF4Linear, replace_by_prequantized_weights
+
+    from .helpers import autocast_cpu, load_golden, synth_params
+
+    T, meta = load_golden("lumina_tiny.safetensors")
+    cfgd = json.loads(meta["config"])
+    with torch.device("meta"):
+        shape_mod = Denoiser(DenoiserConfig(**cfgd))
+    P = {k: v.to(torch.bfloat16).float() for k, v in synth_params(shape_mod, 2, meta["checksum"]).items()}
+    targets = sorted(k[:-len(".weight")] for k, v in P.items() if k.endswith(".weight") and v.dim() == 2
+                     and ("attention" in k or "feed_forward" in k) and "noise_refiner" not in k)
+    assert len(targets) == 15  # qkv, out, w1, w2, w3 of the two main layers and the context refiner
+    # ---- oracle side: quantise (numpy), dequantise (numpy), bf16-round as the kernel's MFMA operand is
+    qsd = {k: v for k, v in P.items()}
+    Pd = dict(P)
+    for n in targets:
+        q = onf4.quantize_nf4(P[n + ".weight"].numpy(), double_quant=True)
+        for suffix, arr in q.items():
+            qsd[n + ".weight" + suffix] = torch.from_numpy(np.ascontiguousarray(arr))
+        Pd[n + ".weight"] = torch.from_numpy(onf4.dequantize_nf4(q)).to(torch.bfloat16).float()
+    assert 0.02 < rel_err(Pd[targets[0] + ".weight"], P[targets[0] + ".weight"]) < 0.2  # really 4-bit
+    lora_names = [n for n in targets if "context_refiner" not in n]  # the LoRA key set of configs/lumina2 + noise_refiner excluded
+    shapes = {}
+    for n in lora_names:
+        w = Pd.pop(n + ".weight")
+        Pd[n + ".linear.weight"] = w
+        shapes[n + ".lora_down.weight"], shapes[n + ".lora_up.weight"] = (4, w.shape[1]), (w.shape[0], 4)
+        Pd[n + ".alpha"] = torch.tensor(1.0)
+    synth = {k: (v * (0.2 if "lora_up" in k else 1.0)).to(torch.bfloat16).float() for k, v in fw.synth_state_dict(shapes, seed=23).items()}
+    cfg = olum.LuminaCfg(**{k: v for k, v in cfgd.items() if k in olum.LuminaCfg.__dataclass_fields__})
+    lora_o = {k: v.clone().to(torch.bfloat16).requires_grad_(True) for k, v in synth.items()}  # adapters are bf16 parameters
+    opt_o = torch.optim.AdamW(list(lora_o.values()), lr=1e-3)
+    losses_o, out_o = [], None
+    for _ in range(3):
+        with autocast_cpu():
+            outs, _, _ = olum.nextdit_forward({**Pd, **lora_o}, cfg, T["noisy"], T["caption"], T["timestep"], T["caption_mask"])
+            o = -torch.stack(outs, 0)
+            loss = ops.flow_loss(T["latents"], T["noise"], o)
+        if out_o is None:
+            out_o = o.detach()
+        loss.backward()
+        opt_o.step()
+        opt_o.zero_grad()
+        losses_o.append(loss.detach().float())
+    # ---- product side: the oracle-quantised state dict goes through the checkpoint path
+    model = Denoiser(DenoiserConfig(**cfgd))
+    replace_by_prequantized_weights(model, qsd)
+    assert sum(isinstance(m, NF4Linear) for m in model.modules()) == 15
+    model.load_state_dict(qsd, strict=True)
+    model = model.to(gpu, torch.bfloat16).requires_grad_(False)
+    PeftTargetConfig(include_keys=["attention", "feed_forward"], exclude_keys=["noise_refiner", "context_refiner"],
+                     config=LoRAConfig(rank=4, alpha=1.0)).replace_to_peft_layer(model)
+    sd = model.state_dict()
+    assert sorted(k for k in sd if ".lora_" in k) == sorted(synth)
+    with torch.no_grad():
+        for k, v in synth.items():
+            sd[k].copy_(v)
+    model.train()
+    params = [p_ for p_ in model.parameters() if p_.requires_grad]
+    assert len(params) == 2 * len(lora_names)
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    g = {k: T[k].to(gpu) for k in ("timestep", "caption", "caption_mask", "noise", "latents", "noisy")}
+    losses, out = [], None
+    for _ in range(3):
+        o, _, _ = model(latents=g["noisy"], timestep=g["timestep"], caption_features=g["caption"], caption_mask=g["caption_mask"])
+        o = -torch.nested.to_padded_tensor(o, padding=0.0)
+        loss = loss_with_predicted_velocity(g["latents"], g["noise"], o.float())
+        if out is None:
+            out = o.detach().cpu()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.detach().float().cpu())
+    assert rel_err(out, out_o) < 2e-2, (nf4_mode, rel_err(out, out_o))
+    torch.testing.assert_close(torch.stack(losses), torch.stack(losses_o), rtol=5e-3, atol=0)
+    assert float(losses[0]) != float(losses[2])  # the adapters did train
+
+
 @pytest.mark.parametrize("M,N,K,r,bias,res", [(4096, 1280, 1280, 4, True, True), (1000, 640, 2048, 8, False, False),
                                               (333, 5120, 640, 16, True, False), (300, 648, 64, 32, True, True),
                                               (777, 1024, 96, 0, True, True), (1, 8, 32, 4, False, False),
