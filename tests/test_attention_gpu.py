@@ -124,3 +124,39 @@ def test_attention_deterministic(gpu):
         outs.append((o.detach(), qq.grad, kk.grad, vv.grad))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize(
+    "B,Hq,Hkv,Sq,Sk,kv_len",
+    [
+        (2, 10, 10, 1024, 1024, None),          # 4 key blocks, few (batch, head) pairs: the key range is sliced, reduce pass
+        (32, 8, 8, 300, 700, None),             # 256 pairs: ONE workgroup walks 3 key blocks, running dQ in its scratch plane
+        (1, 6, 2, 200, 520, None),              # GQA at head_dim 64: three query heads per kv head share a workgroup
+        (2, 4, 4, 333, 390, [390, 131]),        # ragged tiles + key-padding mask ending inside / before the second key block
+        (1, 3, 3, 64, 129, None),               # the smallest key length the one-pass kernel takes
+        (3, 5, 5, 77, 1030, [1030, 1, 600]),    # fewer queries than one tile, five key blocks, a fully masked tail block
+    ],
+)
+def test_attention_one_pass_backward(gpu, B, Hq, Hkv, Sq, Sk, kv_len):
+    """head_dim 64 with more than 128 keys runs the one-pass backward (attn_bwd1_kernel: dQ, dK, dV from one sweep, the
+    running dQ kept per workgroup in an fp32 scratch plane): against the oracle, and bit-identical on a second run."""
+    from vision_ft_amd import kernels
+
+    _run_case(gpu, B, Hq, Hkv, Sq, Sk, 64, kv_len=kv_len, seed=Sq + Sk)
+    g = torch.Generator().manual_seed(9)
+    q, do = (torch.randn(B, Hq, Sq, 64, generator=g).to(torch.bfloat16).to(gpu) for _ in range(2))
+    k, v = (torch.randn(B, Hkv, Sk, 64, generator=g).to(torch.bfloat16).to(gpu) for _ in range(2))
+    kvl = None if kv_len is None else torch.tensor(kv_len, dtype=torch.int32, device=gpu)
+    runs = []
+    for variant in (0, 0, 3):  # 3 = the dq + dkdv pair where the one-pass kernel would run
+        assert kernels._C.lib().vft_attn_variant(variant) == 0
+        try:
+            qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+            kernels.flash_attention(qq, kk, vv, kv_len=kvl).backward(do)
+            runs.append((qq.grad, kk.grad, vv.grad))
+        finally:
+            kernels._C.lib().vft_attn_variant(0)
+    for a, b_ in zip(runs[0], runs[1]):
+        assert torch.equal(a, b_)  # fixed summation order: reproducible
+    for a, c in zip(runs[0], runs[2]):  # the two forms agree to bf16 rounding of differently ordered fp32 sums
+        assert _rel(a, c) < 6e-3, _rel(a, c)

@@ -1737,6 +1737,335 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
     }
 }
 
+// =============================================================================================
+// backward in ONE pass (head_dim 64): dQ, dK and dV from a single sweep — five MFMA products per (query, key) block
+// instead of the seven of the dq + dkdv pair (S and dP are formed once), and one softmax / dS evaluation instead of two.
+//
+// One workgroup = 8 waves = 256 keys of one (batch, kv head): wave w keeps K / V fragments and the dK^T / dV^T
+// accumulators of its 32 keys in registers (two waves per SIMD) and the workgroup sweeps the query tiles (64 queries) of
+// the query heads that share the kv head, exactly like the dK/dV kernel above.  What is new is dQ:
+//   * S and dP are computed with the KEY on the MFMA lane (that is what makes P / dS the B operands of the dV / dK
+//     products), so dS^T — the operand dQ needs, keys in the contraction — does not exist in registers.  Each wave
+//     writes its dS block (bf16) into a [256 keys][64 queries] LDS image: ONE pass through LDS, four 8-byte stores per
+//     32 x 32 block, in the swizzled layout that serves transposed reads.
+//   * dQ^T[d][q] = sum_keys K^T[d][key] dS^T[key][q]: both operands are transposed reads (ds_read_b64_tr_b16) — of a K
+//     image staged once per key block and of the dS image.  The 64 x 64 output is four 32 x 32 blocks; wave w takes
+//     block (w & 3) over the key half (w >> 2) — 8 MFMAs per wave per tile on top of the 32 of S, dP, dV, dK — and the
+//     two waves of a block (w, w ^ 4: one SIMD) swap half of their accumulators through LDS, so each ends up with 8
+//     complete fp32 rows of the block's sum over the workgroup's 256 keys.
+//   * The sum over KEY BLOCKS needs no atomics and no second workgroup: the workgroup walks its key blocks ONE AFTER THE
+//     OTHER (a (batch, head) pair — or a contiguous slice of its key blocks when there are too few pairs to fill the chip
+//     — belongs to one workgroup) and keeps the running dQ in an fp32 scratch plane that only it touches:
+//     read-add-write per tile, the same lane re-reading what it stored one key-block pass earlier (loads bypass L1),
+//     values prefetched one tile ahead.  Fixed order => bit-reproducible.  The first block skips the read, the last one
+//     writes bf16 dQ (scaled) straight to the output; with a sliced key range the planes of the slices are added, in
+//     slice order, by attn_bwd1_reduce_kernel.
+// Cost: the scratch read-modify-write (32 bytes per (query, d) element and key block = 1.25 * 256 flop per byte) and
+// the Q / dO re-read per key block; at 256 keys per block that is ~2.4 + 1.2 TB/s beside an MFMA-bound loop.
+// Q / dO tiles arrive by LDS-DMA in a ring of three buffers; two workgroup barriers per tile.
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
+    static_assert(D == 64, "the one-pass backward is built for head_dim 64 (register budget at two waves per SIMD)");
+    constexpr int KS = D / 16, DT = D / 32, RB = D * 2, BQ = 64, QT = BQ / 32, KB = 256, NB = 3;
+    constexpr int TILE = BQ * RB;                 // bytes of one Q (or dO) tile
+    constexpr int BUFB = 2 * TILE + 512;          // Q | dO | lse[64] | delta[64]
+    constexpr int KIMG = NB * BUFB;               // K image of the key block: [256][D] bf16, swizzled
+    constexpr int DSIMG = KIMG + KB * RB;         // dS image: [256 keys][64 queries] bf16 (128-byte rows), swizzled
+    constexpr int RBS = BQ * 2;                   // bytes per dS row
+    constexpr int XCH = DSIMG + KB * RBS;         // pair exchange: 8 waves x 2 float4 x 64 lanes
+    constexpr int DUMP = XCH + 8 * 2048;          // 256 B per wave for the filler DMAs of waves 2-7
+    typedef DmaTile<D, BQ, 8> Stage;
+    static_assert(Stage::NI == 1 && RBS == RB, "tile geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nkb = (p.Sk + KB - 1) / KB;
+    const int bh = blockIdx.x / p.nsplit, split = blockIdx.x % p.nsplit;
+    if (bh >= p.B * p.Hkv) return;                // block-uniform
+    const int b = bh / p.Hkv, hkv = bh % p.Hkv;
+    const int G = p.Hq / p.Hkv;
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+    const int per_split = (nkb + p.nsplit - 1) / p.nsplit;
+    const int kb0 = split * per_split, kb1 = min(nkb, kb0 + per_split);
+
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dKb = p.dk + b * p.sdk.b + hkv * p.sdk.h;
+    bf16_t* dVb = p.dv + b * p.sdv.b + hkv * p.sdv.h;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((int64_t)(p.Sk - 1) * p.sk.s + D) * 2), 0x00020000);
+    const float sc = p.scale * kLog2e;
+    const int nqt = (p.Sq + BQ - 1) / BQ;
+    const int niter = G * nqt;
+    const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s, ks_s = (int)p.sk.s;
+    const int64_t plane = (int64_t)p.B * p.Hq * nqt * (BQ * D);   // floats per scratch plane
+    float* const scr = p.split_ws + (int64_t)split * plane;
+
+    // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 64 lse
+    // values, wave 1 its delta values, the others a filler
+    auto stage = [&](int it, int buf) {
+        const bool live = it < niter;
+        const int itc = live ? it : 0;
+        const int gq = itc / nqt, t = itc % nqt;
+        const int hq = hkv * G + gq;
+        const bf16_t* Qh_ = p.q + b * p.sq.b + hq * p.sq.h;
+        const bf16_t* dOh_ = p.dout + b * p.sdo.b + hq * p.sdo.h;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
+        char* base = smem + buf * BUFB;
+        const int lim = live ? p.Sq : 0;
+        Stage::issue(rq, base, t * BQ, lim, qs_s);
+        Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
+        const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
+        char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
+        dma4(rs, sdst, (live && w < 2) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+    };
+
+    // fragment addresses (bytes inside a tile of 128-byte rows): row reads: row r, chunk 2 ks + h; transposed reads: rows
+    // 16 kk + 4 h + (i >> 2) (+8), chunk 4 cb + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
+    const int rbase = r * RB + ((h ^ swz_f<RB>(r)) << 4);
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int tbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 4 * h + (i16 >> 2) + 8 * hi;
+        tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;
+    }
+    // where this lane's dS values go: row = its key, 8-byte piece (16-byte chunk c, half h) of the swizzled 128-byte row
+    const int dsrow = (w * 32 + r) * RBS + 8 * h, dsswz = swz_f<RBS>(w * 32 + r);
+    // the dQ block of this wave: d columns 32 (w & 1), queries 32 ((w >> 1) & 1), key half (w >> 2)
+    const int dtw = w & 1, qtw = (w >> 1) & 1, kh = w >> 2;
+    f32x4* const xch = reinterpret_cast<f32x4*>(smem + XCH);
+
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int n0 = kb * KB;
+        const bool first = kb == kb0, last = kb + 1 == kb1;
+        const bool final_store = last && p.nsplit == 1;
+        const int key = n0 + w * 32 + r;
+        const bool kmem = key < p.Sk;   // memory-valid
+        const bool kval = key < kvl;    // participates in the softmax
+        // ---- the key block's operands: K / V fragments of this wave's 32 keys, the K image for the dQ product, the first
+        //      two query tiles.  (Every wave has passed the last reads of the previous block: barrier at the loop's end.)
+        bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
+            Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
+        }
+        DmaTile<D, KB, 8>::issue(rk, smem + KIMG, n0, kvl, ks_s);
+        stage(0, 0);
+        stage(1, 1);
+        f32x16 dK[DT], dV[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                dK[dt][i] = 0.f;
+                dV[dt][i] = 0.f;
+            }
+        // running dQ of the FIRST tile (zero when this is the range's first key block)
+        f32x4 old[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        auto scr_ptr = [&](int it) {  // this wave's 2 x 1 KiB of the tile's 16 KiB: [block w & 3][quad 2 kh + e][lane]
+            const int gq = it / nqt, t = it % nqt;
+            const int64_t tile_id = ((int64_t)b * p.Hq + hkv * G + gq) * nqt + t;
+            return scr + tile_id * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
+        };
+        if (!first && niter > 0) {
+            const float* s0 = scr_ptr(0);
+            old[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0));
+            old[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0 + 256));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        int buf = 0;
+        for (int it = 0; it < niter; ++it) {
+            const char* Qs = smem + buf * BUFB;
+            const char* dOs = Qs + TILE;
+            const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE);
+            const float* dl_s = lse_s + 64;
+            auto rowoff = [&](int ks) { return (rbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256; };
+            auto trfrag = [&](const char* tile, int cb) {  // 32 columns 32 cb.., 16 rows from `tile`
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (tbase[0] ^ (cb << 6))));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (tbase[1] ^ (cb << 6))));
+                return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+            // ---- phase 1: S, dP -> P, dS; dV, dK; dS into the LDS image ------------------------------------------
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const char* Qq = Qs + qt * 32 * RB;
+                const char* dOq = dOs + qt * 32 * RB;
+                f32x16 S, dP;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    S[i] = 0.f;
+                    dP[i] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    S = mfma32(*reinterpret_cast<const bf16x8*>(Qq + rowoff(ks)), Kf[ks], S);
+                    dP = mfma32(*reinterpret_cast<const bf16x8*>(dOq + rowoff(ks)), Vf[ks], dP);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
+                        if (!kval) pv = 0.f;
+                        S[4 * g4 + i] = pv;
+                        dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                    }
+                }
+                bf16x8 Pf[2], dSf[2];
+                Pf[0] = pack8(S, 0);
+                Pf[1] = pack8(S, 1);
+                dSf[0] = pack8(dP, 0);
+                dSf[1] = pack8(dP, 1);
+                // dS block -> image: registers 8 s + 4 e .. + 3 are queries 32 qt + 16 s + 8 e + 4 h .. + 3 of this lane's key
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const u32x4 v = __builtin_bit_cast(u32x4, dSf[s_]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = qt * 4 + 2 * s_ + e;
+                        *reinterpret_cast<u32x2*>(smem + DSIMG + dsrow + (((c ^ dsswz) & 7) << 4)) = u32x2{v[2 * e], v[2 * e + 1]};
+                    }
+                }
+                // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        dV[dt] = mfma32(trfrag(dOq + kk * 16 * RB, dt), Pf[kk], dV[dt]);
+                        dK[dt] = mfma32(trfrag(Qq + kk * 16 * RB, dt), dSf[kk], dK[dt]);
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // B1: the dS image is complete; tile it-1's buffer is free
+            stage(it + 2, buf == 0 ? NB - 1 : buf - 1);
+            // ---- phase 2: dQ^T block of this wave over its key half ----------------------------------------------
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int krow = (kh * 8 + kk) * 16;
+                acc = mfma32(trfrag(smem + KIMG + krow * RB, dtw), trfrag(smem + DSIMG + krow * RBS, qtw), acc);
+            }
+            // swap halves with the partner wave (w ^ 4, the same block over the other key half): keep quads 2 kh, 2 kh + 1
+            f32x4* xo = xch + (w * 2) * 64 + lane;
+            if (kh == 0) {
+                xo[0] = f32x4{acc[8], acc[9], acc[10], acc[11]};
+                xo[64] = f32x4{acc[12], acc[13], acc[14], acc[15]};
+            } else {
+                xo[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                xo[64] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            }
+            // every DMA and global load of this wave issued before this tile's stage() has landed (the next tile's share,
+            // the running dQ of this tile), and last tile's stores are done; the DMAs just issued may still fly
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3) : "memory");
+            __builtin_amdgcn_s_barrier();  // B2
+            const f32x4* xi = xch + ((w ^ 4) * 2) * 64 + lane;
+            const f32x4 p0 = xi[0], p1 = xi[64];
+            f32x4 sum0, sum1;
+            if (kh == 0) {
+                sum0 = f32x4{acc[0], acc[1], acc[2], acc[3]} + p0 + old[0];
+                sum1 = f32x4{acc[4], acc[5], acc[6], acc[7]} + p1 + old[1];
+            } else {
+                sum0 = f32x4{acc[8], acc[9], acc[10], acc[11]} + p0 + old[0];
+                sum1 = f32x4{acc[12], acc[13], acc[14], acc[15]} + p1 + old[1];
+            }
+            const int gq = it / nqt, t = it % nqt;
+            if (final_store) {
+                const int q = t * BQ + qtw * 32 + r;
+                if (q < p.Sq) {
+                    bf16_t* dst = p.dq + b * p.sdq.b + (hkv * G + gq) * p.sdq.h + (int64_t)q * p.sdq.s + dtw * 32 + 16 * kh + 4 * h;
+                    const float s_ = p.scale;
+                    store4(dst, sum0[0] * s_, sum0[1] * s_, sum0[2] * s_, sum0[3] * s_);
+                    store4(dst + 8, sum1[0] * s_, sum1[1] * s_, sum1[2] * s_, sum1[3] * s_);
+                }
+            } else {
+                float* s0 = scr_ptr(it);
+                *reinterpret_cast<f32x4*>(s0) = sum0;
+                *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
+            }
+            if (!first && it + 1 < niter) {  // the running dQ of the next tile: a whole tile of time to arrive
+                const float* s1 = scr_ptr(it + 1);
+                old[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1));
+                old[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1 + 256));
+            }
+            buf = buf == NB - 1 ? 0 : buf + 1;
+        }
+        // ---- dK, dV of this key block ----
+        if (kmem) {
+            const float s_ = p.scale;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = dt * 32 + 8 * e + 4 * h;
+                    store4(dKb + (int64_t)key * p.sdk.s + d, dK[dt][4 * e] * s_, dK[dt][4 * e + 1] * s_, dK[dt][4 * e + 2] * s_,
+                           dK[dt][4 * e + 3] * s_);
+                    store4(dVb + (int64_t)key * p.sdv.s + d, dV[dt][4 * e], dV[dt][4 * e + 1], dV[dt][4 * e + 2], dV[dt][4 * e + 3]);
+                }
+        }
+        // nothing of this block may still be in flight towards LDS, and every wave is past its last reads of the K image /
+        // the ring, before the next block's prologue overwrites them
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// dQ = scale * (sum over the key-range slices' scratch planes, in slice order) -> bf16; one thread = one float4 of the
+// kernel's native layout [tile][block][quad][lane]
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd1_reduce_kernel(AttnParams p) {
+    constexpr int BQ = 64;
+    const int nqt = (p.Sq + BQ - 1) / BQ;
+    const int64_t plane = (int64_t)p.B * p.Hq * nqt * (BQ * D);
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e * 4 >= plane) return;
+    const int lane = (int)(e & 63), quad = (int)((e >> 6) & 3), blk = (int)((e >> 8) & 3);
+    const int64_t tile_id = e >> 10;
+    const int t = (int)(tile_id % nqt);
+    const int bhq = (int)(tile_id / nqt), b = bhq / p.Hq, hq = bhq % p.Hq;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(p.split_ws + (int64_t)s * plane + e * 4);
+        a.x += x.x, a.y += x.y, a.z += x.z, a.w += x.w;
+    }
+    const int q = t * BQ + (blk >> 1) * 32 + (lane & 31);
+    if (q >= p.Sq) return;
+    const int d = (blk & 1) * 32 + 8 * quad + 4 * (lane >> 5);
+    store4(p.dq + b * p.sdq.b + hq * p.sdq.h + (int64_t)q * p.sdq.s + d, a.x * p.scale, a.y * p.scale, a.z * p.scale, a.w * p.scale);
+}
+
+// delta[b, h, q] = sum_d dO * O (the dq kernel of the two-kernel form computes it on the side); 8 lanes per query row
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+    constexpr int LPR = D / 8;  // lanes per row (16 bytes each)
+    const int64_t rows = (int64_t)p.B * p.Hq * p.Sq;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = idx / LPR;
+    const int c = (int)(idx % LPR) * 8;
+    float dl = 0.f;
+    if (row < rows) {
+        const int q = (int)(row % p.Sq);
+        const int bhq = (int)(row / p.Sq), b = bhq / p.Hq, hq = bhq % p.Hq;
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(p.o + b * p.so.b + hq * p.so.h + (int64_t)q * p.so.s + c);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.dout + b * p.sdo.b + hq * p.sdo.h + (int64_t)q * p.sdo.s + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)o[j] * (float)g[j];
+    }
+#pragma unroll
+    for (int o_ = 1; o_ < LPR; o_ <<= 1) dl += __shfl_xor(dl, o_, 64);
+    if (row < rows && c == 0) p.delta[row] = dl;
+}
+
 // dk / dv = Σ_split partial (fixed order), dk scaled; one thread = 4 consecutive d of one key
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_split_reduce_kernel(AttnParams p) {
@@ -1787,6 +2116,45 @@ __host__ inline int dkdv_nsplit(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     for (int ns = 2; ns <= 4 && eff(best) < 0.88; ++ns)
         if (niter / ns >= 16 && eff(ns) > eff(best) + 0.05) best = ns;
     return best;
+}
+
+// One-pass backward (attn_bwd1_kernel): head_dim 64 and more than one 128-key block of keys (short key sequences — the
+// 77-token cross-attention — would fill 30 % of a 256-key block: they stay on the dq + dkdv pair).  Returns the number of
+// key-range slices per (batch, kv head), 0 when the kernel does not apply.  A workgroup costs one pass per key block of its
+// slice; the chip holds 256 workgroups: fewest rounds x passes wins, ties go to fewer slices (no reduce pass at 1).
+__host__ inline int bwd1_slices(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
+    (void)Hq, (void)Sq;
+    if (D != 64 || Sk <= 128 || g_attn_variant != 0) return 0;
+    const int64_t bhk = (int64_t)B * Hkv, nkb = (Sk + 255) / 256;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int ns = 1; ns <= nkb && ns <= 16; ++ns) {
+        const int64_t cost = ((bhk * ns + 255) / 256) * ((nkb + ns - 1) / ns) * 16 + (ns > 1 ? 1 : 0);
+        if (best_cost < 0 || cost < best_cost) best_cost = cost, best = ns;
+    }
+    return best;
+}
+__host__ inline int64_t bwd1_plane_floats(int B, int Hq, int Sq, int D) { return (int64_t)B * Hq * ((Sq + 63) / 64) * (64 * D); }
+
+template <int D>
+int launch_bwd1(AttnParams p, hipStream_t st) {
+    constexpr size_t lds = 3 * (2 * 64 * D * 2 + 512) + 256 * D * 2 + 256 * 128 + 8 * 2048 + 8 * 256;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int64_t rows = (int64_t)p.B * p.Hq * p.Sq * (D / 8);
+    hipLaunchKernelGGL(attn_delta_kernel<D>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+    VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
+    hipLaunchKernelGGL(attn_bwd1_kernel<D>, dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
+    VFT_CHECK_LAUNCH("vft_attn_bwd(one pass)");
+    if (p.nsplit > 1) {
+        const int64_t n = bwd1_plane_floats(p.B, p.Hq, p.Sq, D) / 4;
+        hipLaunchKernelGGL(attn_bwd1_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+        VFT_CHECK_LAUNCH("vft_attn_bwd(dq reduce)");
+    }
+    return 0;
 }
 
 int check_strides(const char* name, const int64_t* s) {
@@ -1855,7 +2223,8 @@ int launch_fwd2(const AttnParams& p, hipStream_t st) {
 
 template <int D, int BQ>
 int launch_bwd(const AttnParams& p, hipStream_t st) {
-    if (D != 96 && g_attn_variant != 1) {
+    const int variant = g_attn_variant == 3 ? 0 : g_attn_variant;  // 3 = "the pair where the one-pass kernel would run": the default pair
+    if (D != 96 && variant != 1) {
         if constexpr (D != 96) {
             constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t);  // double-buffered K | V tiles, unpadded
             static bool attr = false;
@@ -1879,7 +2248,7 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), lds, st, p);  // also writes delta
         VFT_CHECK_LAUNCH("vft_attn_bwd(dq)");
     }
-    if (D != 96 && g_attn_variant == 0) {
+    if (D != 96 && variant == 0) {
         if constexpr (D != 96) {
             constexpr int BQ3 = D <= 64 ? 64 : 32;
             constexpr size_t lds = 4 * (2 * BQ3 * D * 2 + 512) + 4 * 256;  // four Q|dO|stats buffers + filler slots
@@ -1897,7 +2266,7 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
             hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
             VFT_CHECK_LAUNCH("vft_attn_bwd(split reduce)");
         }
-    } else if (D >= 128 && g_attn_variant == 2) {
+    } else if (D >= 128 && variant == 2) {
         if constexpr (D >= 128) {
             // three Q|dO|stats buffers + the pairs' exchange slabs (partials, packed P/dS) + one dump slot per wave
             constexpr size_t lds = 3 * (2 * 32 * D * 2 + 512) + 4 * 8 * 64 * 16 + 4 * 4 * 64 * 16 + 8 * 256;
@@ -1966,7 +2335,7 @@ extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 extern "C" int vft_attn_variant(int variant) {
-    VFT_CHECK_ARG(variant >= 0 && variant <= 2, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels) or 2 (8-wave dK/dV)", variant);
+    VFT_CHECK_ARG(variant >= 0 && variant <= 3, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels), 2 (8-wave dK/dV) or 3 (dq + dkdv pair where the one-pass backward would run)", variant);
     g_attn_variant = variant;
     return 0;
 }
@@ -1975,6 +2344,8 @@ extern "C" int vft_attn_variant(int variant) {
 extern "C" int64_t vft_attn_bwd_workspace(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return 0;
     const int64_t delta_floats = ((int64_t)B * Hq * Sq + 3) / 4 * 4;
+    const int n1 = bwd1_slices(B, Hq, Hkv, Sq, Sk, D);
+    if (n1 > 0) return delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D);  // running-dQ scratch plane(s)
     const int ns = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
     return delta_floats + (ns > 1 ? 2 * (int64_t)ns * B * Hkv * Sk * D : 0);
 }
@@ -2013,10 +2384,15 @@ extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const v
     // workspace = delta [B*Hq*Sq] followed (16-byte aligned) by the split-Q partials when the caller provided room
     const int64_t delta_floats = ((int64_t)B * Hq * Sq + 3) / 4 * 4;
     VFT_CHECK_ARG(ws_floats >= (int64_t)B * Hq * Sq, "vft_attn_bwd: workspace too small (%lld floats)", (long long)ws_floats);
-    p.nsplit = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
-    if (p.nsplit > 1 && ws_floats < delta_floats + 2 * (int64_t)p.nsplit * B * Hkv * Sk * D) p.nsplit = 1;
     p.split_ws = delta_ws + delta_floats;
     hipStream_t st = (hipStream_t)stream;
+    const int n1 = bwd1_slices(B, Hq, Hkv, Sq, Sk, D);
+    if (n1 > 0 && ws_floats >= delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D)) {
+        p.nsplit = n1;
+        return launch_bwd1<64>(p, st);
+    }
+    p.nsplit = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
+    if (p.nsplit > 1 && ws_floats < delta_floats + 2 * (int64_t)p.nsplit * B * Hkv * Sk * D) p.nsplit = 1;
     switch (D) {
         case 64: return launch_bwd<64, 64>(p, st);
         case 96: return launch_bwd<96, 64>(p, st);
