@@ -502,6 +502,26 @@ def test_linear_trained_gradients_and_in_place_accumulation(gpu):
     assert rel_err(wg.grad.float().cpu(), 2 * wr.grad) < 8e-3
     assert not torch.equal(before, wg.grad)
     assert rel_err(bg.grad.float().cpu(), 2 * br.grad) < 8e-3  # vft_colsum accumulated into the existing bias gradient
+    # the skip connection in the forward GEMM's epilogue (round 3: all three GEMMs of a trainable layer on our kernels;
+    # FeedForward-sized output = more than 30 weight-gradient tiles, which round 2 left to the library)
+    Cff = 5120
+    w2, res = _bf(g, Cin, Cff, sc=Cff**-0.5), _bf(g, B, S, Cin)
+    x2, gy2 = _bf(g, B, S, Cff), _bf(g, B, S, Cin, sc=0.02)
+    x2r, w2r, rr = (t.float().requires_grad_(True) for t in (x2, w2, res))
+    (rr + torch.nn.functional.linear(x2r, w2r)).backward(gy2.float())
+    x2g, w2g, rg = (t.to(gpu).requires_grad_(True) for t in (x2, w2, res))
+    y2 = kernels.linear_trained(x2g, w2g, None, rg)
+    assert rel_err(y2.float().cpu(), res.float() + torch.nn.functional.linear(x2.float(), w2.float())) < 5e-3
+    y2.backward(gy2.to(gpu))
+    for got, ref in ((x2g.grad, x2r.grad), (w2g.grad, w2r.grad), (rg.grad, rr.grad)):
+        assert rel_err(got.float().cpu(), ref) < 6e-3, rel_err(got.float().cpu(), ref)
+    wide = _bf(g, Cff * 2, Cin, sc=Cin**-0.5).to(gpu).requires_grad_(True)  # 640 -> 10240: 120 weight-gradient tiles
+    xw = x.to(gpu).requires_grad_(True)
+    gyw = _bf(g, B, S, Cff * 2, sc=0.02)
+    kernels.linear_trained(xw, wide, None).backward(gyw.to(gpu))
+    ref_w = gyw.float().reshape(-1, Cff * 2).t() @ x.float().reshape(-1, Cin)
+    assert rel_err(wide.grad.float().cpu(), ref_w) < 6e-3
+    assert rel_err(xw.grad.float().cpu(), gyw.float() @ wide.detach().float().cpu()) < 6e-3
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 64, 64), (1, 640, 320, 41, 104), (3, 192, 1280, 48, 32),

@@ -42,7 +42,8 @@ struct AttnParams {
     bf16_t* dk;
     bf16_t* dv;
     float* lse;             // [B, Hq, Sq] natural-log LSE of scaled scores
-    float* delta;           // [B, Hq, Sq] rowsum(dO*O)
+    float* delta;           // [B, Hq, Sq] rowsum(dO*O)   (one-pass backward: its negative)
+    float* nlse;            // one-pass backward: [B, Hq, Sq] -lse / scale (the S accumulators start from it)
     const int32_t* kv_len;  // [B] or nullptr
     float* split_ws;        // bwd, nsplit > 1: fp32 partial dK | dV, each [nsplit][B*Hkv][Sk][D]
     int nsplit;
@@ -157,6 +158,16 @@ __device__ __forceinline__ bf16x8 ldg_frag(const bf16_t* p, bool ok) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
     return z;
+}
+
+// Make the compiler wait HERE for an ordinary (VGPR-destination) load: an asm statement that takes the value as an operand.
+// Needed in front of every loop that keeps LDS-DMA in flight: hipcc cannot count its own loads past a DMA, so a fragment
+// loaded before the loop and first used inside it costs an `s_waitcnt vmcnt(0)` INSIDE the loop — which drains the DMA
+// ring on every iteration (seen in the ISA of the dK/dV kernel: a four-buffer ring that never had more than one tile in
+// flight).  After the pin no ordinary load is pending and the loop's only vmcnt waits are the counted ones written here.
+template <class T>
+__device__ __forceinline__ void pin_loaded(T& x) {
+    asm volatile("" : "+v"(x));
 }
 
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
@@ -356,9 +367,45 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_fwd_kernel(AttnPa
 // which serves both the row reads of K (ds_read_b128, 32 rows x one chunk) and the transposed reads of V
 // (ds_read_b64_tr_b16) without bank conflicts; the swizzle sits on the DMA's per-lane SOURCE chunk.
 // =============================================================================================
+// LDS-DMA (buffer_load ... offen lds) issued through INLINE ASM, on purpose.  With the builtin the compiler knows an LDS write
+// is pending on the VM counter, cannot tell what it aliases, and puts `s_waitcnt vmcnt(0)` in front of the first
+// ds_read_b64_tr_b16 that follows (seen in the ISA of every kernel here that mixes the two: the dK/dV kernel's ring of four
+// buffers drained on every tile, one L2 round trip per tile).  Hidden in asm, the DMA is invisible to that bookkeeping: the
+// kernels' own counted `s_waitcnt vmcnt(N)` + barrier (which they had all along) are then the only waits.
+//   * One statement issues a GROUP of N pieces (N x 1 KiB: consecutive LDS destinations, one descriptor): M0 (the LDS
+//     destination, compiler-reserved) is saved and restored once per group; `s_nop 4` covers a descriptor / base SGPR written
+//     just before (SALU or v_readfirstlane -> VMEM read: 5 wait states), `s_nop 0` each M0 write -> LDS-DMA hazard.
+//   * No "memory" clobber: a DMA only has to stay behind the wait + barrier that freed its destination, and those statements
+//     are volatile asm WITH the clobber (volatile statements keep their order; the compiler's own LDS accesses cannot cross
+//     the clobbering one).  Without the clobber the compiler may still schedule its LDS reads and MFMAs around the group.
 typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lds_void_t*)p; }
+#define VFT_DMA_ONE(k, KB_) "s_add_u32 m0, %1, " #KB_ "\n\ts_nop 0\n\tbuffer_load_dwordx4 %" #k ", %2, 0 offen lds\n\t"
+template <int N>
+__device__ __forceinline__ void dma16_group(__amdgpu_buffer_rsrc_t r, char* l, const int (&voff)[N]) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8, "pieces per group");
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(l));
+    unsigned keep;
+    if constexpr (N == 1) {
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t" VFT_DMA_ONE(3, 0) "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "s"(r), "v"(voff[0]) : "scc");
+    } else if constexpr (N == 2) {
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t" VFT_DMA_ONE(3, 0) VFT_DMA_ONE(4, 1024) "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "s"(r), "v"(voff[0]), "v"(voff[1]) : "scc");
+    } else if constexpr (N == 4) {
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t" VFT_DMA_ONE(3, 0) VFT_DMA_ONE(4, 1024) VFT_DMA_ONE(5, 2048) VFT_DMA_ONE(6, 3072) "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "s"(r), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]) : "scc");
+    } else {
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\t" VFT_DMA_ONE(3, 0) VFT_DMA_ONE(4, 1024) VFT_DMA_ONE(5, 2048) VFT_DMA_ONE(6, 3072)
+                     VFT_DMA_ONE(7, 4096) VFT_DMA_ONE(8, 5120) VFT_DMA_ONE(9, 6144) VFT_DMA_ONE(10, 7168) "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(dst), "s"(r), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7])
+                     : "scc");
+    }
+}
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 16, voff, 0, 0, 0);
+    const int v[1] = {voff};
+    dma16_group<1>(r, l, v);
 }
 // (256-byte and longer rows: 16 chunks per bank window, f as above; 128-byte rows (head_dim 64): two rows share a bank window
 // and a row has 8 chunks: f(r) = (((r >> 1) & 1) << 2) | ((r >> 2) & 3) — the same two access patterns, conflict-free)
@@ -371,7 +418,7 @@ __device__ __forceinline__ int swz_f(int row) {
 // rows x (D*2)-byte tile by LDS-DMA, 512 threads: wave-instruction i covers 1024 bytes = 1024/(2D) rows.  Nothing is
 // kept per instruction: the lane's row and swizzled source chunk are recomputed at issue (a few VALU operations per
 // 1 KiB moved; the register file is what these kernels are short of).
-template <int D, int ROWS, int NW = 8>
+template <int D, int ROWS, int NW = 8, bool ASM = true>
 struct DmaTile {
     static constexpr int RB = D * 2;                  // bytes per row
     static constexpr int NI = ROWS * RB / 1024 / NW;  // instructions per wave per tile
@@ -379,13 +426,23 @@ struct DmaTile {
     // rows [row0, row0 + ROWS) of the tensor behind `rs` (row stride in elements); rows >= row_limit read zeros
     static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int row0, int row_limit, int row_stride_elems) {
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        int voffs[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int byte = (wv * NI + q) * 1024 + lane * 16;
             const int r = byte / RB, slot = (byte % RB) >> 4;
             const int c = (slot & ~15) | ((slot & 15) ^ swz_f<RB>(r));
             const int voff = (row0 + r) * row_stride_elems * 2 + c * 16;
-            dma16(rs, lds_tile + (wv * NI + q) * 1024, row0 + r < row_limit ? voff : OOBV);
+            voffs[q] = row0 + r < row_limit ? voff : OOBV;
+        }
+        if constexpr (ASM) {
+            dma16_group<NI>(rs, lds_tile + wv * NI * 1024, voffs);
+        } else {  // the builtin form: the compiler sees the pending LDS writes (see above) — measured faster in the head_dim
+                  // >= 128 backward kernels (one wave per SIMD: it spreads the pieces among the MFMAs), A/B on one MI355X:
+                  // AuraFlow backward 5.97 ms against 6.25 with the asm groups
+#pragma unroll
+            for (int q = 0; q < NI; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds_tile + (wv * NI + q) * 1024), 16, voffs[q], 0, 0, 0);
         }
     }
 };
@@ -415,6 +472,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
     bf16x8 Qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) pin_loaded(Qf[ks]);
 
     f32x16 O[DT];
 #pragma unroll
@@ -590,6 +649,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2s_kernel(AttnParams p) {
     bf16x8 Qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) pin_loaded(Qf[ks]);
 
     f32x16 O[DT];
 #pragma unroll
@@ -924,7 +985,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 template <int D>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq3_kernel(AttnParams p) {
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;
-    typedef DmaTile<D, 64, 4> Stage;
+    typedef DmaTile<D, 64, 4, false> Stage;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -973,6 +1034,14 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq3_kernel(At
         if (qok && h == 0) p.delta[srow] = dl;
     }
     const float sc = p.scale * kLog2e;
+    float lse2p = lse2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        pin_loaded(Qf[ks]);
+        pin_loaded(dOf[ks]);
+    }
+    pin_loaded(lse2p);
+    pin_loaded(dl);
 
     f32x16 dQ[DT];
 #pragma unroll
@@ -1044,7 +1113,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq3_kernel(At
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(S[i] * sc - lse2);
+                const float pv = __builtin_amdgcn_exp2f(S[i] * sc - lse2p);
                 S[i] = pv * (dP[i] - dl);
             }
             dSf[kt * 2] = pack8(S, 0);
@@ -1291,8 +1360,24 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
 // per tile (its share of Q and dO, 8 floats of lse / delta), so one counted vmcnt per tile retires its share of the
 // next tile one barrier before the first group reads it.
 // =============================================================================================
-__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
+// the same with the `nt` cache policy: the load bypasses the CU's vector L1 (used for data this CU stored itself earlier
+// in the launch — the running-dQ scratch of the one-pass backward)
+__device__ __forceinline__ void dma16_nt(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(l));
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dst), "v"(voff), "s"(r));
+}
+__device__ __forceinline__ void dma4_builtin(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 4, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t r, char* l, int voff) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(l));
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dst), "v"(voff), "s"(r));
 }
 
 template <int D>
@@ -1303,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
     constexpr int XA = 3 * BUFB;                   // follower -> leader: partial S, dP: 4 pairs x 8 float4 x 64 lanes
     constexpr int XB = XA + 4 * 8 * 64 * 16;       // leader -> follower: packed P, dS:   4 pairs x 4 uint4 x 64 lanes
     constexpr int DUMP = XB + 4 * 4 * 64 * 16;     // 256 B per wave: where the filler DMAs of waves 2-7 land
-    constexpr int NDMA = 2 * DmaTile<D, BQ>::NI + 1;  // DMA instructions per wave per tile
+    constexpr int NDMA = 2 * DmaTile<D, BQ, 8, false>::NI + 1;  // DMA instructions per wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), grp = w >> 2, pair = w >> 1, g = w & 1;
@@ -1331,6 +1416,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
         Kh[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + (g * HK + ks) * 16 + 8 * h, kval);
         Vh[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + (g * HK + ks) * 16 + 8 * h, kval);
     }
+#pragma unroll
+    for (int ks = 0; ks < HK; ++ks) {
+        pin_loaded(Kh[ks]);
+        pin_loaded(Vh[ks]);
+    }
     f32x16 dK[HT], dV[HT];
 #pragma unroll
     for (int dt = 0; dt < HT; ++dt)
@@ -1345,7 +1435,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
     const int niter = (n0 < kvl) ? G * nqt : 0;   // fully masked key blocks get zero gradients
     const int per_split = (niter + p.nsplit - 1) / p.nsplit;
     const int it0 = split * per_split, it1 = min(niter, it0 + per_split);
-    typedef DmaTile<D, BQ> Stage;
+    typedef DmaTile<D, BQ, 8, false> Stage;
     const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s;
     // this wave's share of tile `it`: Q, dO, and one 4-byte DMA — wave 0 brings the tile's 32 lse values, wave 1 its 32
     // delta values, the other waves issue a filler into a dump slot so that EVERY wave has the same number of DMAs per
@@ -1363,7 +1453,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
         const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
-        dma4(rs, sdst, (w < 2 && lane < 32) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        dma4_builtin(rs, sdst, (w < 2 && lane < 32) ? (t * BQ + lane) * 4 : (int)0x80000000u);
     };
     if (it0 < it1) stage(it0, 0);
     if (it0 + 1 < it1) stage(it0 + 1, 1);
@@ -1534,7 +1624,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
     constexpr int TILE = BQ * RB;           // bytes of one Q (or dO) tile
     constexpr int BUFB = 2 * TILE + 512;    // Q | dO | lse[BQ] | delta[BQ]  (256-byte slots: one 4-byte DMA each)
     constexpr int DUMP = NB * BUFB;         // 256 B per wave for the filler DMAs of waves 2, 3
-    typedef DmaTile<D, BQ, 4> Stage;
+    typedef DmaTile<D, BQ, 4, false> Stage;
     constexpr int NDMA = 2 * Stage::NI + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -1561,6 +1651,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
     for (int ks = 0; ks < KS; ++ks) {
         Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
         Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        pin_loaded(Kf[ks]);
+        pin_loaded(Vf[ks]);
     }
     f32x16 dK[DT], dV[DT];
 #pragma unroll
@@ -1595,7 +1690,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
         const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
-        dma4(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        dma4_builtin(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
     };
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) stage(it0 + j, j);
@@ -1775,6 +1870,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     constexpr int RBS = BQ * 2;                   // bytes per dS row
     constexpr int XCH = DSIMG + KB * RBS;         // pair exchange: 8 waves x 2 float4 x 64 lanes
     constexpr int DUMP = XCH + 8 * 2048;          // 256 B per wave for the filler DMAs of waves 2-7
+    constexpr int OLD = DUMP + 8 * 256;           // running dQ of the next tile: 2 KiB per wave, by LDS-DMA from the scratch plane
     typedef DmaTile<D, BQ, 8> Stage;
     static_assert(Stage::NI == 1 && RBS == RB, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1802,8 +1898,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     const int64_t plane = (int64_t)p.B * p.Hq * nqt * (BQ * D);   // floats per scratch plane
     float* const scr = p.split_ws + (int64_t)split * plane;
 
-    // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 64 lse
-    // values, wave 1 its delta values, the others a filler
+    // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 64
+    // -lse / scale values, wave 1 its -delta values (both prepared by attn_delta_kernel), the others a filler
     auto stage = [&](int it, int buf) {
         const bool live = it < niter;
         const int itc = live ? it : 0;
@@ -1818,7 +1914,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         Stage::issue(rq, base, t * BQ, lim, qs_s);
         Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
         const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.nlse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
         dma4(rs, sdst, (live && w < 2) ? (t * BQ + lane) * 4 : (int)0x80000000u);
     };
@@ -1854,6 +1950,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
             Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
             Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin_loaded(Kf[ks]);
+            pin_loaded(Vf[ks]);
+        }
         DmaTile<D, KB, 8>::issue(rk, smem + KIMG, n0, kvl, ks_s);
         stage(0, 0);
         stage(1, 1);
@@ -1865,18 +1966,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 dK[dt][i] = 0.f;
                 dV[dt][i] = 0.f;
             }
-        // running dQ of the FIRST tile (zero when this is the range's first key block)
-        f32x4 old[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        auto scr_ptr = [&](int it) {  // this wave's 2 x 1 KiB of the tile's 16 KiB: [block w & 3][quad 2 kh + e][lane]
+        auto tile_id_of = [&](int it) {
             const int gq = it / nqt, t = it % nqt;
-            const int64_t tile_id = ((int64_t)b * p.Hq + hkv * G + gq) * nqt + t;
-            return scr + tile_id * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
+            return ((int64_t)b * p.Hq + hkv * G + gq) * nqt + t;
         };
-        if (!first && niter > 0) {
-            const float* s0 = scr_ptr(0);
-            old[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0));
-            old[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0 + 256));
-        }
+        auto scr_ptr = [&](int it) {  // this wave's 2 x 1 KiB of the tile's 16 KiB: [block w & 3][quad 2 kh + e][lane]
+            return scr + tile_id_of(it) * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
+        };
+        // The running dQ of tile `it` travels scratch plane -> LDS by DMA one tile ahead (no VGPR-destination load in the
+        // loop: beside hidden DMAs the compiler would wait vmcnt(0) for it and drain the ring).  Nothing to read in the
+        // range's first key block or past the last tile: an out-of-range offset delivers zeros.
+        auto old_dma = [&](int it) {
+            const bool live = !first && it < niter;
+            const float* tb = scr + tile_id_of(live ? it : 0) * (BQ * D);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)tb, 0, BQ * D * 4, 0x00020000);
+            const int voff = live ? ((w & 3) * 1024 + (2 * kh) * 256 + lane * 4) * 4 : (int)0x80000000u;
+            dma16_nt(ro, smem + OLD + w * 2048, voff);
+            dma16_nt(ro, smem + OLD + w * 2048 + 1024, live ? voff + 1024 : voff);
+        };
+        old_dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
@@ -1892,40 +2000,67 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (tbase[1] ^ (cb << 6))));
                 return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             };
-            // ---- phase 1: S, dP -> P, dS; dV, dK; dS into the LDS image ------------------------------------------
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
+            // ---- phase 1: S, dP -> P, dS; dV, dK; dS into the LDS image.  Written as an explicit software pipeline over the
+            //      two 32-query sub-tiles (R: row fragments + row constants, M1: S / dP, T: transposed fragments, V: softmax on
+            //      the VALU, W: dS stores, M2: dV / dK) with scheduling barriers between the stages: left to itself the
+            //      compiler re-uses one fragment register set and every MFMA waits for its own LDS read.
+            //      Row constants as the INITIAL ACCUMULATORS: S starts from -lse / scale and dP from -delta, so that
+            //      p = exp2(sc * S) and dS = p * dP need no per-element subtraction (the accumulator register index is the
+            //      query, so the constants are four 16-byte LDS reads per accumulator).
+            bf16x8 qa[KS], da[KS], ta[2 * DT], tc[2 * DT];
+            f32x16 S, dP;
+            auto read_rows = [&](int qt) {  // R
                 const char* Qq = Qs + qt * 32 * RB;
                 const char* dOq = dOs + qt * 32 * RB;
-                f32x16 S, dP;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    S[i] = 0.f;
-                    dP[i] = 0.f;
-                }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    S = mfma32(*reinterpret_cast<const bf16x8*>(Qq + rowoff(ks)), Kf[ks], S);
-                    dP = mfma32(*reinterpret_cast<const bf16x8*>(dOq + rowoff(ks)), Vf[ks], dP);
+                    qa[ks] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(ks));
+                    da[ks] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(ks));
                 }
+            };
+            auto init_acc = [&](int qt) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
-                        if (!kval) pv = 0.f;
-                        S[4 * g4 + i] = pv;
-                        dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                        S[4 * g4 + i] = l4[i];
+                        dP[4 * g4 + i] = d4[i];
                     }
+                }
+            };
+            read_rows(0);
+            init_acc(0);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const char* Qq = Qs + qt * 32 * RB;
+                const char* dOq = dOs + qt * 32 * RB;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {  // M1
+                    S = mfma32(qa[ks], Kf[ks], S);
+                    dP = mfma32(da[ks], Vf[ks], dP);
+                }
+#pragma unroll
+                for (int st = 0; st < 2 * DT; ++st) {  // T: in flight while the softmax runs
+                    ta[st] = trfrag(dOq + (st & 1) * 16 * RB, st >> 1);
+                    tc[st] = trfrag(Qq + (st & 1) * 16 * RB, st >> 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {  // V
+                    float pv = __builtin_amdgcn_exp2f(S[i] * sc);
+                    if (!kval) pv = 0.f;
+                    S[i] = pv;
+                    dP[i] = pv * dP[i];
                 }
                 bf16x8 Pf[2], dSf[2];
                 Pf[0] = pack8(S, 0);
                 Pf[1] = pack8(S, 1);
                 dSf[0] = pack8(dP, 0);
                 dSf[1] = pack8(dP, 1);
-                // dS block -> image: registers 8 s + 4 e .. + 3 are queries 32 qt + 16 s + 8 e + 4 h .. + 3 of this lane's key
+                // W: dS block -> image: registers 8 s + 4 e .. + 3 are queries 32 qt + 16 s + 8 e + 4 h .. + 3 of this lane's key
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
                     const u32x4 v = __builtin_bit_cast(u32x4, dSf[s_]);
@@ -1935,26 +2070,42 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                         *reinterpret_cast<u32x2*>(smem + DSIMG + dsrow + (((c ^ dsswz) & 7) << 4)) = u32x2{v[2 * e], v[2 * e + 1]};
                     }
                 }
-                // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+                if (qt + 1 < QT) read_rows(qt + 1);  // the next sub-tile's row fragments fly during this one's dV / dK MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                // M2: dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        dV[dt] = mfma32(trfrag(dOq + kk * 16 * RB, dt), Pf[kk], dV[dt]);
-                        dK[dt] = mfma32(trfrag(Qq + kk * 16 * RB, dt), dSf[kk], dK[dt]);
-                    }
+                for (int st = 0; st < 2 * DT; ++st) {
+                    dV[st >> 1] = mfma32(ta[st], Pf[st & 1], dV[st >> 1]);
+                    dK[st >> 1] = mfma32(tc[st], dSf[st & 1], dK[st >> 1]);
+                }
+                if (qt + 1 < QT) init_acc(qt + 1);  // (issued behind the MFMAs: S / dP are free again, the reads overlap their execution)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // B1: the dS image is complete; tile it-1's buffer is free
             stage(it + 2, buf == 0 ? NB - 1 : buf - 1);
-            // ---- phase 2: dQ^T block of this wave over its key half ----------------------------------------------
+            // ---- phase 2: dQ^T block of this wave over its key half, operand fragments four steps ahead --------------
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            {
+                const char* kim = smem + KIMG + kh * 128 * RB;
+                const char* sim = smem + DSIMG + kh * 128 * RBS;
+                constexpr int QF = 4;
+                bf16x8 ka[QF], sa[QF];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int krow = (kh * 8 + kk) * 16;
-                acc = mfma32(trfrag(smem + KIMG + krow * RB, dtw), trfrag(smem + DSIMG + krow * RBS, qtw), acc);
+                for (int j = 0; j < QF; ++j) {
+                    ka[j] = trfrag(kim + j * 16 * RB, dtw);
+                    sa[j] = trfrag(sim + j * 16 * RBS, qtw);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const bf16x8 a_ = ka[kk % QF], b_ = sa[kk % QF];
+                    if (kk + QF < 8) {
+                        ka[kk % QF] = trfrag(kim + (kk + QF) * 16 * RB, dtw);
+                        sa[kk % QF] = trfrag(sim + (kk + QF) * 16 * RBS, qtw);
+                    }
+                    acc = mfma32(a_, b_, acc);
+                }
             }
             // swap halves with the partner wave (w ^ 4, the same block over the other key half): keep quads 2 kh, 2 kh + 1
             f32x4* xo = xch + (w * 2) * 64 + lane;
@@ -1965,19 +2116,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 xo[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
                 xo[64] = f32x4{acc[4], acc[5], acc[6], acc[7]};
             }
-            // every DMA and global load of this wave issued before this tile's stage() has landed (the next tile's share,
-            // the running dQ of this tile), and last tile's stores are done; the DMAs just issued may still fly
+            // everything this wave issued before this tile's stage() has landed or retired: the next tile's Q / dO share
+            // (issued one tile ago), this tile's running dQ (issued after the previous B2), last tile's stores; only the
+            // three DMAs just issued may still fly
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3) : "memory");
             __builtin_amdgcn_s_barrier();  // B2
             const f32x4* xi = xch + ((w ^ 4) * 2) * 64 + lane;
+            const f32x4* oi = reinterpret_cast<const f32x4*>(smem + OLD + w * 2048) + lane;
             const f32x4 p0 = xi[0], p1 = xi[64];
+            const f32x4 o0 = oi[0], o1 = oi[64];
             f32x4 sum0, sum1;
             if (kh == 0) {
-                sum0 = f32x4{acc[0], acc[1], acc[2], acc[3]} + p0 + old[0];
-                sum1 = f32x4{acc[4], acc[5], acc[6], acc[7]} + p1 + old[1];
+                sum0 = f32x4{acc[0], acc[1], acc[2], acc[3]} + p0 + o0;
+                sum1 = f32x4{acc[4], acc[5], acc[6], acc[7]} + p1 + o1;
             } else {
-                sum0 = f32x4{acc[8], acc[9], acc[10], acc[11]} + p0 + old[0];
-                sum1 = f32x4{acc[12], acc[13], acc[14], acc[15]} + p1 + old[1];
+                sum0 = f32x4{acc[8], acc[9], acc[10], acc[11]} + p0 + o0;
+                sum1 = f32x4{acc[12], acc[13], acc[14], acc[15]} + p1 + o1;
             }
             const int gq = it / nqt, t = it % nqt;
             if (final_store) {
@@ -1993,11 +2147,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 *reinterpret_cast<f32x4*>(s0) = sum0;
                 *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
             }
-            if (!first && it + 1 < niter) {  // the running dQ of the next tile: a whole tile of time to arrive
-                const float* s1 = scr_ptr(it + 1);
-                old[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1));
-                old[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1 + 256));
-            }
+            old_dma(it + 1);  // (the reads of this tile's copy above are complete: their values went into the sums)
             buf = buf == NB - 1 ? 0 : buf + 1;
         }
         // ---- dK, dV of this key block ----
@@ -2044,7 +2194,8 @@ __global__ __launch_bounds__(256) void attn_bwd1_reduce_kernel(AttnParams p) {
     store4(p.dq + b * p.sdq.b + hq * p.sdq.h + (int64_t)q * p.sdq.s + d, a.x * p.scale, a.y * p.scale, a.z * p.scale, a.w * p.scale);
 }
 
-// delta[b, h, q] = sum_d dO * O (the dq kernel of the two-kernel form computes it on the side); 8 lanes per query row
+// Row constants of the one-pass backward: delta[b, h, q] = -sum_d dO * O and nlse = -lse / scale (the initial dP / S
+// accumulators); 8 lanes per query row.  (The dq kernel of the two-kernel form computes its delta on the side.)
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     constexpr int LPR = D / 8;  // lanes per row (16 bytes each)
@@ -2063,7 +2214,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int o_ = 1; o_ < LPR; o_ <<= 1) dl += __shfl_xor(dl, o_, 64);
-    if (row < rows && c == 0) p.delta[row] = dl;
+    if (row < rows && c == 0) {
+        p.delta[row] = -dl;
+        p.nlse[row] = -p.lse[row] / p.scale;
+    }
 }
 
 // dk / dv = Σ_split partial (fixed order), dk scaled; one thread = 4 consecutive d of one key
@@ -2126,19 +2280,20 @@ __host__ inline int bwd1_slices(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     (void)Hq, (void)Sq;
     if (D != 64 || Sk <= 128 || g_attn_variant != 0) return 0;
     const int64_t bhk = (int64_t)B * Hkv, nkb = (Sk + 255) / 256;
+    // time ~ rounds of the 256 resident workgroups x key-block passes per workgroup.  Slicing (ns > 1) costs one fp32 plane
+    // per slice and a reduce pass over all of them (measured: 16 planes of 252 MB = 0.7 ms beside a 3 ms kernel), so it
+    // has to buy at least a quarter of the time, and never more than 4 slices.
+    auto cost = [&](int64_t ns) { return ((bhk * ns + 255) / 256) * ((nkb + ns - 1) / ns); };
     int best = 1;
-    int64_t best_cost = -1;
-    for (int ns = 1; ns <= nkb && ns <= 16; ++ns) {
-        const int64_t cost = ((bhk * ns + 255) / 256) * ((nkb + ns - 1) / ns) * 16 + (ns > 1 ? 1 : 0);
-        if (best_cost < 0 || cost < best_cost) best_cost = cost, best = ns;
-    }
+    for (int ns = 2; ns <= nkb && ns <= 4; ++ns)
+        if (4 * cost(ns) <= 3 * cost(best)) best = ns;
     return best;
 }
 __host__ inline int64_t bwd1_plane_floats(int B, int Hq, int Sq, int D) { return (int64_t)B * Hq * ((Sq + 63) / 64) * (64 * D); }
 
 template <int D>
 int launch_bwd1(AttnParams p, hipStream_t st) {
-    constexpr size_t lds = 3 * (2 * 64 * D * 2 + 512) + 256 * D * 2 + 256 * 128 + 8 * 2048 + 8 * 256;
+    constexpr size_t lds = 3 * (2 * 64 * D * 2 + 512) + 256 * D * 2 + 256 * 128 + 8 * 2048 + 8 * 256 + 8 * 2048;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2345,7 +2500,7 @@ extern "C" int64_t vft_attn_bwd_workspace(int B, int Hq, int Hkv, int Sq, int Sk
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || Sq <= 0 || Sk <= 0) return 0;
     const int64_t delta_floats = ((int64_t)B * Hq * Sq + 3) / 4 * 4;
     const int n1 = bwd1_slices(B, Hq, Hkv, Sq, Sk, D);
-    if (n1 > 0) return delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D);  // running-dQ scratch plane(s)
+    if (n1 > 0) return 2 * delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D);  // -delta, -lse/scale, running-dQ plane(s)
     const int ns = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
     return delta_floats + (ns > 1 ? 2 * (int64_t)ns * B * Hkv * Sk * D : 0);
 }
@@ -2387,8 +2542,10 @@ extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const v
     p.split_ws = delta_ws + delta_floats;
     hipStream_t st = (hipStream_t)stream;
     const int n1 = bwd1_slices(B, Hq, Hkv, Sq, Sk, D);
-    if (n1 > 0 && ws_floats >= delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D)) {
+    if (n1 > 0 && ws_floats >= 2 * delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D)) {
         p.nsplit = n1;
+        p.nlse = delta_ws + delta_floats;
+        p.split_ws = delta_ws + 2 * delta_floats;
         return launch_bwd1<64>(p, st);
     }
     p.nsplit = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);

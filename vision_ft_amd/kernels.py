@@ -1634,13 +1634,18 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = No
     return _Linear.apply(x, weight, bias, residual)
 
 
-# Trainable projections (full fine-tune).  Forward and data gradient stay on the table-tuned library GEMMs (see
-# `linear_eligible`); the WEIGHT gradient of the small-output projections — the attention's square q / k / v / out
-# matrices, 280 of the SDXL step's 323 Linears — runs on vft_linear_wgrad, which beats the tuned library there (measured on
-# MI355X, B = 16: 1280 x 1280 over 16 384 tokens 87 vs 124 us, 640 x 640 over 65 536 tokens 103 vs 177 us) and accumulates
-# straight into the parameter's gradient (no AccumulateGrad pass).  Large outputs (the FeedForward matrices) are faster on
-# the library and stay there.
+# Trainable projections (full fine-tune, BASELINE config 2).  Round 3: ALL THREE GEMMs of such a layer run on our kernels —
+#   forward        y = x W^T + b (+ residual)   vft_linear_fwd (lin8), bias and skip add in the epilogue
+#   data gradient  dx = dy W                    vft_linear_fwd on a transposed copy of W made in the backward pass (the weight
+#                                               changes every step; 2.6 B parameters = ~3 ms of copies per step)
+#   weight grad    dW = dy^T x                  vft_linear_wgrad (wg8), accumulated straight into the parameter's gradient
+# Measured on one MI355X at the B = 24 shapes (tools/exp/trained_linear_bench.py; library = hipBLASLt with the committed
+# solution table): forward 86.2 vs 82.4 ms per step (the K = 640 / 1280 FeedForward up-projections lose: 10-20 K-tiles per
+# output tile), data gradient 80.3 vs 87.0, weight gradients 124.0 vs 168.3 with everything on wg8 (the library is 2.5x
+# slower on the small attention matrices; wg8 is 3-15 % slower on the three FeedForward shapes).  VFT_TRAINED_LIBRARY=1
+# restores the round-2 split (library forward / data gradient / large weight gradients) for A/B runs.
 TRAINED_LINEAR_WGRAD = os.environ.get("VFT_TRAINED_WGRAD", "1") != "0"  # A/B switch
+TRAINED_ON_LIBRARY = os.environ.get("VFT_TRAINED_LIBRARY", "0") != "0"   # A/B switch: round-2 behaviour
 
 
 def trained_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -1653,23 +1658,33 @@ def trained_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def _wgrad_on_kernel(M: int, R: int, Cc: int) -> bool:
-    """Small outputs (at most 30 tiles of 256 x 256: the attention projections) — there the split-reduction kernel beats the
-    tuned library; the FeedForward matrices are faster on the library."""
+    """Round 2: only small outputs (at most 30 tiles of 256 x 256: the attention projections) took the split-reduction
+    kernel; now every shape its 32-bit offsets cover does, unless the library split is asked for."""
     tiles = ((R + 255) // 256) * ((Cc + 255) // 256)
-    return tiles <= 30 and (M + 130) * max(R, Cc) * 2 < 2**31
+    return (tiles <= 30 or not TRAINED_ON_LIBRARY) and (M + 130) * max(R, Cc) * 2 < 2**31
+
+
+def _gemm_on_kernel(weight: torch.Tensor) -> bool:
+    """Forward / data gradient of a trainable weight on vft_linear_fwd: both reduction lengths multiples of 64."""
+    return not TRAINED_ON_LIBRARY and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
 
 
 class _LinearTrained(torch.autograd.Function):
-    """F.linear of a trainable weight (src/models/sdxl/denoiser.py:62-64,135-137): library GEMMs forward and for the data
-    gradient, vft_linear_wgrad for the weight gradient, accumulated into `weight.grad` when the trainer has pointed it into
-    its flat buffer."""
+    """F.linear of a trainable weight (src/models/sdxl/denoiser.py:62-64,135-137,183-204), optionally + residual."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual):
         ctx.save_for_backward(x, weight)
         ctx.params = (weight, bias)
-        with _Timed("lib_gemm_fwd", 2.0 * (x.numel() // x.shape[-1]) * weight.shape[0] * weight.shape[1]):
-            return F.linear(x, weight, bias)
+        ctx.has_res = residual is not None
+        x2 = _rows(x)
+        if _gemm_on_kernel(weight) and x2.stride(1) == 1:
+            with torch.cuda.device(x.device):
+                y2 = linear_fused(x2, weight, _bf16_or_none(bias), residual=_bf16_rows(residual))
+            return y2.view(*x.shape[:-1], weight.shape[0])
+        with _Timed("lib_gemm_fwd", 2.0 * x2.shape[0] * weight.shape[0] * weight.shape[1]):
+            y = F.linear(x, weight, bias)
+        return y if residual is None else residual + y
 
     @staticmethod
     def backward(ctx, dy):
@@ -1679,8 +1694,12 @@ class _LinearTrained(torch.autograd.Function):
         dx = dw = db = None
         flops = 2.0 * dy2.shape[0] * weight.shape[0] * weight.shape[1]
         if ctx.needs_input_grad[0]:
-            with _Timed("lib_gemm_dgrad", flops):
-                dx = (dy2 @ weight).view(x.shape)
+            if _gemm_on_kernel(weight):
+                with torch.cuda.device(dy.device):
+                    dx = linear_fused(dy2, _transposed_weight(weight), None).view(x.shape)
+            else:
+                with _Timed("lib_gemm_dgrad", flops):
+                    dx = (dy2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             g = _grad_target(wparam)
             if _wgrad_on_kernel(dy2.shape[0], weight.shape[0], weight.shape[1]) and linear_wgrad_eligible(dy2, x2):
@@ -1694,13 +1713,15 @@ class _LinearTrained(torch.autograd.Function):
                     dw = dy2.t() @ x2
         if bparam is not None and ctx.needs_input_grad[2]:
             db = colsum(dy2, bparam)
-        return dx, dw, db
+        dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres
 
 
-def linear_trained(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+def linear_trained(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
+                   residual: torch.Tensor | None = None) -> torch.Tensor:
     _ready(x, weight)
     _require_gpu(x, weight, bias)
-    return _LinearTrained.apply(x, weight, bias)
+    return _LinearTrained.apply(x, weight, bias, residual)
 
 
 # =============================================================================================

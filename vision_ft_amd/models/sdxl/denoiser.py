@@ -49,8 +49,7 @@ def _proj_residual(layer: nn.Module, h: torch.Tensor, residual: torch.Tensor | N
     if type(layer) is nn.Linear and kernels.linear_eligible(h, layer.weight):
         return kernels.linear(h, layer.weight, layer.bias, residual)
     if type(layer) is nn.Linear and kernels.trained_linear_eligible(h, layer.weight):
-        y = kernels.linear_trained(h, layer.weight, layer.bias)  # full fine-tune: own weight-gradient kernel
-        return y if residual is None else residual + y
+        return kernels.linear_trained(h, layer.weight, layer.bias, residual)  # full fine-tune: all three GEMMs on own kernels
     return layer(h) if residual is None else residual + layer(h)
 
 
