@@ -42,8 +42,19 @@ constexpr int OOB = (int)0x80000000u;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* l, int voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)l, 16, voff, 0, 0, 0);
+// Two LDS-DMA pieces (2 x 1 KiB, consecutive LDS destinations) in ONE inline-asm statement.  Through the builtin the compiler
+// sees a pending LDS write on the VM counter and puts `s_waitcnt vmcnt(0)` in front of the next ds_read_b64_tr_b16 — in
+// this kernel that was EVERY phase of the main loop (eight vmcnt(0) per reduction tile in the round-2 ISA): the three
+// half-tiles "in flight" were drained as soon as they were issued.  Hidden in asm the DMAs are outside that bookkeeping
+// and the counted waits written below are the only ones (see attn.hip for the M0 / s_nop rules of the statement).
+__device__ __forceinline__ void dma16x2(__amdgpu_buffer_rsrc_t r, unsigned char* l, int voff0, int voff1) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)l);
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %2, 0 offen lds\n\t"
+                 "s_add_u32 m0, %1, 1024\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dst), "s"(r), "v"(voff0), "v"(voff1)
+                 : "scc");
 }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -138,8 +149,8 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     auto stage_a = [&](int t, int buf, int hh) {
         unsigned char* dst = smw + buf * TILE + hh * HALF + wv * DX * 1024;
         const int adv = t * stepa;
-#pragma unroll
-        for (int q = 0; q < DX; ++q) dma16(ra, dst + q * 1024, (int)((unsigned)ga[hh][q] + (unsigned)adv));
+        static_assert(DX == 2 && DW == 2, "dma16x2 issues two pieces");
+        dma16x2(ra, dst, (int)((unsigned)ga[hh][0] + (unsigned)adv), (int)((unsigned)ga[hh][1] + (unsigned)adv));
     };
     auto stage_b = [&](int t, int buf, int hh) {
         unsigned char* dst = smw + buf * TILE + 2 * HALF + hh * HALF + wv * DW * 1024;
@@ -152,14 +163,15 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
                 while (s_oh >= p.cH) s_oh -= p.cH;
             }
             const bool rowok = (unsigned)(s_oh + tdy[hh]) < (unsigned)p.cH;
+            int vo[DW];
 #pragma unroll
             for (int q = 0; q < DW; ++q) {
                 const bool ok = rowok && (unsigned)(s_ow + 4 * q + lrow + tdx[hh]) < (unsigned)p.cW;
-                dma16(rb, dst + q * 1024, ok ? (int)((unsigned)gb[hh][q] + (unsigned)adv) : OOB);
+                vo[q] = ok ? (int)((unsigned)gb[hh][q] + (unsigned)adv) : OOB;
             }
+            dma16x2(rb, dst, vo[0], vo[1]);
         } else {
-#pragma unroll
-            for (int q = 0; q < DW; ++q) dma16(rb, dst + q * 1024, (int)((unsigned)gb[hh][q] + (unsigned)adv));
+            dma16x2(rb, dst, (int)((unsigned)gb[hh][0] + (unsigned)adv), (int)((unsigned)gb[hh][1] + (unsigned)adv));
         }
     };
 
