@@ -62,8 +62,17 @@ __device__ __attribute__((aligned(16))) bf16_t g_zero_page[32];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
+// LDS-DMA through INLINE ASM (global_load_lds_dwordx4, M0 = wave-uniform LDS destination, saved / restored in the
+// statement).  With the builtin the compiler sees a pending LDS write on the VM counter and drains it (`s_waitcnt vmcnt(0)`)
+// in front of the next LDS access it cannot disambiguate — in the NF4 modes that is the dequantisation's look-up-table read
+// right behind the counted staging wait (seen in the round-2 ISA: `vmcnt(4)` followed by `vmcnt(0)` in every stage), in the
+// transposed mode every ds_read_b64_tr_b16.  Hidden in asm, the ring's counted waits below are the only ones.
 __device__ __forceinline__ void glds16(const bf16_t* g, bf16_t* l) {
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)l);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst));
 }
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {

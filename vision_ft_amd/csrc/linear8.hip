@@ -216,6 +216,11 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
 
     const int nkt = p.K / 64;
     // One K-tile = four phases.  has1 / has2: tiles t+1 / t+2 exist (wave-uniform).
+    // (Tried in round 3, measured A/B on one MI355X and reverted: issuing each phase's fragment reads in the TAIL of the MFMA
+    // burst that frees their registers — X0 / W0 of the next tile behind phase 3, W1 behind phase 0, X1 behind phase 1 —
+    // instead of at the head of the consuming phase.  6 % SLOWER on the SDXL shapes (forward 85.5 -> 90.7 ms per step,
+    // data gradient 80.1 -> 84.0): the heads are already shorter than the 256-cycle bursts they run beside, so the reads
+    // were hidden where they were, and behind the burst they lengthen the computing group's own interval.)
     auto tile = [&](int t, auto BUFc, bool has1, bool has2) {
         constexpr int BUF = decltype(BUFc)::value;
         const unsigned char* tb = sm8 + BUF * TILE;
