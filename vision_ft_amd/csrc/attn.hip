@@ -28,6 +28,11 @@
 
 namespace {
 
+// A/B build switch: 1 = the dq3 / dkdv3 backward kernels issue their LDS-DMA through the inline-asm groups too
+#ifndef VFT_ATTN_BWD_ASM_DMA
+#define VFT_ATTN_BWD_ASM_DMA 0
+#endif
+
 struct Str3 {
     int64_t b, h, s;  // element strides of batch, head, sequence; head_dim is contiguous
 };
@@ -437,9 +442,10 @@ struct DmaTile {
         }
         if constexpr (ASM) {
             dma16_group<NI>(rs, lds_tile + wv * NI * 1024, voffs);
-        } else {  // the builtin form: the compiler sees the pending LDS writes (see above) — measured faster in the head_dim
-                  // >= 128 backward kernels (one wave per SIMD: it spreads the pieces among the MFMAs), A/B on one MI355X:
-                  // AuraFlow backward 5.97 ms against 6.25 with the asm groups
+        } else {  // the builtin form: the compiler sees the pending LDS writes (see above).  Kept for the head_dim 64 dq / dkdv
+                  // pair (no difference measured there).  At head_dim >= 128 the asm groups first measured SLOWER (AuraFlow
+                  // backward 6.25 ms against 5.97) while every MFMA still waited for its own LDS read; with the explicit
+                  // fragment pipeline of the dK/dV kernel in place they win (5.71 against 5.88), so they are the default there
 #pragma unroll
             for (int q = 0; q < NI; ++q)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds_tile + (wv * NI + q) * 1024), 16, voffs[q], 0, 0, 0);
@@ -985,7 +991,7 @@ __global__ __launch_bounds__(256, (D <= 96 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 template <int D>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dq3_kernel(AttnParams p) {
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, TILE = 64 * RB;
-    typedef DmaTile<D, 64, 4, false> Stage;
+    typedef DmaTile<D, 64, 4, (VFT_ATTN_BWD_ASM_DMA != 0 || D >= 128)> Stage;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1624,7 +1630,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
     constexpr int TILE = BQ * RB;           // bytes of one Q (or dO) tile
     constexpr int BUFB = 2 * TILE + 512;    // Q | dO | lse[BQ] | delta[BQ]  (256-byte slots: one 4-byte DMA each)
     constexpr int DUMP = NB * BUFB;         // 256 B per wave for the filler DMAs of waves 2, 3
-    typedef DmaTile<D, BQ, 4, false> Stage;
+    typedef DmaTile<D, BQ, 4, (VFT_ATTN_BWD_ASM_DMA != 0 || D >= 128)> Stage;
     constexpr int NDMA = 2 * Stage::NI + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -1690,7 +1696,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
         const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
-        dma4_builtin(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        if constexpr (VFT_ATTN_BWD_ASM_DMA != 0 || D >= 128) dma4(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        else dma4_builtin(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
     };
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) stage(it0 + j, j);
@@ -1726,67 +1733,147 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0 + (tbase[1] ^ x)));
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
+        if constexpr (D >= 128) {
+            // One wave per SIMD: nothing but this wave's own instruction stream hides an LDS round trip, and left to itself
+            // the compiler serialises read -> wait -> MFMA (round-2 ISA at head_dim 256: 63 waits for 64 MFMAs, 54 of them
+            // lgkmcnt(0) / lgkmcnt(1)).  Explicit software pipeline instead: the fragments of CH k-steps are read as one
+            // group, two groups in flight (double-buffered registers), scheduling barriers keep a group's reads ahead of
+            // the previous group's MFMAs.
+            constexpr int CH = D >= 256 ? 2 : 4, NG1 = KS / CH, NG2 = 2 * DT / CH;  // (head_dim 256: groups of 4 spill 24 registers)
+            static_assert(KS % CH == 0 && (2 * DT) % CH == 0, "chunking");
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const char* Qq = Qs + qt * 32 * RB;
-            const char* dOq = dOs + qt * 32 * RB;
-            // ---- S = Q K^T, dP = dO V^T: fragment reads run PF steps ahead ----
-            bf16x8 qa[PF], da[PF];
+            for (int qt = 0; qt < QT; ++qt) {
+                const char* Qq = Qs + qt * 32 * RB;
+                const char* dOq = dOs + qt * 32 * RB;
+                bf16x8 qa[2][CH], da[2][CH];
+                auto load1 = [&](int g) {
 #pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                qa[j] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(j));
-                da[j] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(j));
-            }
-            f32x16 S, dP;
+                    for (int j = 0; j < CH; ++j) {
+                        qa[g & 1][j] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(g * CH + j));
+                        da[g & 1][j] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(g * CH + j));
+                    }
+                };
+                f32x16 S, dP;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                S[i] = 0.f;
-                dP[i] = 0.f;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = qa[ks % PF], c = da[ks % PF];
-                if (ks + PF < KS) {
-                    qa[ks % PF] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(ks + PF));
-                    da[ks % PF] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(ks + PF));
+                for (int i = 0; i < 16; ++i) {
+                    S[i] = 0.f;
+                    dP[i] = 0.f;
                 }
-                S = mfma32(a, Kf[ks], S);
-                dP = mfma32(c, Vf[ks], dP);
-            }
-            // the first transposed fragments of the second half travel while the softmax runs on the VALU
-            bf16x8 ta[TF], tc[TF];
+                load1(0);
 #pragma unroll
-            for (int j = 0; j < TF; ++j) {
-                ta[j] = trfrag(dOq, j);
-                tc[j] = trfrag(Qq, j);
-            }
+                for (int g = 0; g < NG1; ++g) {
+                    if (g + 1 < NG1) load1(g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+                    for (int j = 0; j < CH; ++j) {
+                        S = mfma32(qa[g & 1][j], Kf[g * CH + j], S);
+                        dP = mfma32(da[g & 1][j], Vf[g * CH + j], dP);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bf16x8 ta[2][CH], tc[2][CH];
+                auto load2 = [&](int g) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
-                    if (!kval) pv = 0.f;
-                    S[4 * g4 + i] = pv;
-                    dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                    for (int j = 0; j < CH; ++j) {
+                        ta[g & 1][j] = trfrag(dOq, g * CH + j);
+                        tc[g & 1][j] = trfrag(Qq, g * CH + j);
+                    }
+                };
+                load2(0);  // travels while the softmax runs on the VALU
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
+                        if (!kval) pv = 0.f;
+                        S[4 * g4 + i] = pv;
+                        dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                    }
+                }
+                bf16x8 Pf[2], dSf[2];
+                Pf[0] = pack8(S, 0);
+                Pf[1] = pack8(S, 1);
+                dSf[0] = pack8(dP, 0);
+                dSf[1] = pack8(dP, 1);
+#pragma unroll
+                for (int g = 0; g < NG2; ++g) {
+                    if (g + 1 < NG2) load2(g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const int st = g * CH + j;
+                        dV[st >> 1] = mfma32(ta[g & 1][j], Pf[st & 1], dV[st >> 1]);
+                        dK[st >> 1] = mfma32(tc[g & 1][j], dSf[st & 1], dK[st >> 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            bf16x8 Pf[2], dSf[2];
-            Pf[0] = pack8(S, 0);
-            Pf[1] = pack8(S, 1);
-            dSf[0] = pack8(dP, 0);
-            dSf[1] = pack8(dP, 1);
-            // ---- dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS ----
-#pragma unroll
-            for (int st = 0; st < 2 * DT; ++st) {
-                const bf16x8 a = ta[st % TF], c = tc[st % TF];
-                if (st + TF < 2 * DT) {
-                    ta[st % TF] = trfrag(dOq, st + TF);
-                    tc[st % TF] = trfrag(Qq, st + TF);
+        } else {
+    #pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const char* Qq = Qs + qt * 32 * RB;
+                const char* dOq = dOs + qt * 32 * RB;
+                // ---- S = Q K^T, dP = dO V^T: fragment reads run PF steps ahead ----
+                bf16x8 qa[PF], da[PF];
+    #pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    qa[j] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(j));
+                    da[j] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(j));
                 }
-                dV[st >> 1] = mfma32(a, Pf[st & 1], dV[st >> 1]);
-                dK[st >> 1] = mfma32(c, dSf[st & 1], dK[st >> 1]);
+                f32x16 S, dP;
+    #pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    S[i] = 0.f;
+                    dP[i] = 0.f;
+                }
+    #pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 a = qa[ks % PF], c = da[ks % PF];
+                    if (ks + PF < KS) {
+                        qa[ks % PF] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(ks + PF));
+                        da[ks % PF] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(ks + PF));
+                    }
+                    S = mfma32(a, Kf[ks], S);
+                    dP = mfma32(c, Vf[ks], dP);
+                }
+                // the first transposed fragments of the second half travel while the softmax runs on the VALU
+                bf16x8 ta[TF], tc[TF];
+    #pragma unroll
+                for (int j = 0; j < TF; ++j) {
+                    ta[j] = trfrag(dOq, j);
+                    tc[j] = trfrag(Qq, j);
+                }
+    #pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
+                        if (!kval) pv = 0.f;
+                        S[4 * g4 + i] = pv;
+                        dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                    }
+                }
+                bf16x8 Pf[2], dSf[2];
+                Pf[0] = pack8(S, 0);
+                Pf[1] = pack8(S, 1);
+                dSf[0] = pack8(dP, 0);
+                dSf[1] = pack8(dP, 1);
+                // ---- dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS ----
+    #pragma unroll
+                for (int st = 0; st < 2 * DT; ++st) {
+                    const bf16x8 a = ta[st % TF], c = tc[st % TF];
+                    if (st + TF < 2 * DT) {
+                        ta[st % TF] = trfrag(dOq, st + TF);
+                        tc[st % TF] = trfrag(Qq, st + TF);
+                    }
+                    dV[st >> 1] = mfma32(a, Pf[st & 1], dV[st >> 1]);
+                    dK[st >> 1] = mfma32(c, dSf[st & 1], dK[st >> 1]);
+                }
             }
         }
         // this wave's share of tile it+1 has landed (issued three tiles ago); tiles it+2, it+3 stay in flight
