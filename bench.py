@@ -201,8 +201,9 @@ def per_call_roofline(prof: dict) -> dict:
 # hand-written kernels by family: (profile-key prefixes, HIP kernel name, roofline that bounds it)
 FAMILIES = {
     "linear_gemm": (("linear_fwd",), "lin8_kernel (vft_linear_fwd: base GEMM + bias + LoRA rank extension + skip, forward and data gradient)", "mfma"),
-    "attention_bwd": (("attn_bwd",), "attn_bwd_dkdv_kernel + attn_bwd_dq_kernel", "mfma"),
-    "attention_fwd": (("attn_fwd",), "attn_fwd_kernel", "mfma"),
+    "attention_bwd": (("attn_bwd",), "attn_bwd1_kernel (one pass: head_dim 64 self-attention) / attn_bwd_dq3_kernel + attn_bwd_dkdv3_kernel (head_dim >= 128, "
+                                     "short key sequences) / attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (head_dim 96)", "mfma"),
+    "attention_fwd": (("attn_fwd",), "attn_fwd_kernel (head_dim 64 / 96) / attn_fwd2_kernel (head_dim >= 128)", "mfma"),
     "conv3x3": (("conv3x3_fwd", "conv3x3_dgrad"), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
     "weight_grad": (("linear_wgrad", "conv3x3_wgrad"), "wg8_kernel (vft_linear_wgrad / vft_conv3x3_wgrad: weight gradients of trainable projections and 3x3 convolutions)", "mfma"),
     "gemm_nf4": (("gemm_nf4",), "NF4 dequantising projection GEMM (vft_linear_nf4)", "mfma"),
@@ -233,14 +234,15 @@ def family_table(prof: dict, steps: int) -> dict:
 
 
 def pmc_traffic(family: str):
-    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r02_b_pmc_hbm_traffic.csv, falling
+    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r03_a_pmc_hbm_traffic.csv, falling
     back to earlier files: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py,
     gfx950 x2 fetch correction applied) — measured at the shape named in the note, not inside this run."""
     import csv
 
-    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkdv3_kernel"}.get(family)
+    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd1_kernel",
+            "weight_grad": "wg8_kernel<false>"}.get(family)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r03_a_pmc_hbm_traffic.csv", "r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         try:
             for row in csv.DictReader(open(os.path.join(root, name))):
                 if want and row["kernel"] == want:

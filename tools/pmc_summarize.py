@@ -13,6 +13,10 @@ ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
     "attn_bwd_dkdv_kernel": 6 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "attn_bwd_dq3_kernel": 5 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "attn_bwd_dkdv3_kernel": 6 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    # round 3, one-pass backward: q, k, v, dO read + dq, dk, dv written (the running-dQ scratch and the Q / dO re-reads per
+    # key block come on top: that is what this row is for); its row-constant pre-pass reads O and dO
+    "attn_bwd1_kernel": 7 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "attn_delta_kernel": 2 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "lora_rows_kernelILi4ELb1": (2 * 98304 * 640 + 4 * 98304 * 5120) / 1e6,
     "lora_rows_kernelILi4ELb0": (2 * 98304 * 5120 + 4 * 98304 * 640) / 1e6,
     "lora_wgrad_partial": 2 * 98304 * (640 + 5120) / 1e6,
