@@ -1920,6 +1920,238 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
 }
 
 // =============================================================================================
+// backward dK/dV, head_dim 96 (Lumina2: 24 query / 8 kv heads x 96), round 3: 4 waves x 32 keys, 64-query tiles, two
+// workgroups per CU (two waves per SIMD that do not share barriers).  The round-1 kernel for this head_dim staged Q / dO
+// through registers (24 VGPRs held across the tile), spilled inside the loop and — as its ISA showed — waited lgkmcnt(0)
+// in front of 50 of its 48 MFMAs' operand reads: one LDS round trip per MFMA.  This one:
+//   * Q / dO tiles by asm LDS-DMA into rows PADDED to 256 bytes (the 192-byte rows of head_dim 96 do not divide a DMA piece;
+//     with 256-byte rows the swizzled image of the head_dim 128 / 256 kernels applies unchanged; pad chunks are requested
+//     out of range and arrive as zeros), double-buffered, one barrier per tile;
+//   * the explicit stage pipeline of the one-pass kernel (R: row fragments, M1: S / dP, T: transposed fragments in flight
+//     under the softmax, M2: dV / dK; the next sub-tile's row fragments issued before this one's M2).
+// GQA: loops over the query heads of the kv head; short key sequences split their query tiles (nsplit) like the others.
+// =============================================================================================
+template <int D, int ROWS, int NW>
+struct DmaTilePad {  // ROWS x D bf16 -> LDS rows of 256 bytes (D * 2 <= 256), swizzle on the source chunk
+    static constexpr int NI = ROWS * 256 / 1024 / NW;
+    static_assert(D * 2 <= 256 && ROWS * 256 % (1024 * NW) == 0, "geometry");
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int row0, int row_limit, int row_stride_elems) {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        int voffs[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int byte = (wv * NI + q) * 1024 + lane * 16;
+            const int r = byte >> 8, slot = (byte & 255) >> 4;
+            const int c = slot ^ swz_f<256>(r);
+            voffs[q] = (row0 + r < row_limit && c < D / 8) ? (row0 + r) * row_stride_elems * 2 + c * 16 : (int)0x80000000u;
+        }
+        dma16_group<NI>(rs, lds_tile + wv * NI * 1024, voffs);
+    }
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = 256, BQ = 64, QT = 2;
+    constexpr int TILE = BQ * RB;            // bytes of one Q (or dO) tile in LDS
+    constexpr int BUFB = 2 * TILE + 512;     // Q | dO | lse[64] | delta[64]
+    constexpr int DUMP = 2 * BUFB;           // 256 B per wave for the filler DMAs of waves 2, 3
+    typedef DmaTilePad<D, BQ, 4> Stage;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ktile, bh;
+    if (!xcd_map(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv, ktile, bh)) return;  // block-uniform
+    const int split = ktile % p.nsplit;
+    ktile /= p.nsplit;
+    const int b = bh / p.Hkv, hkv = bh % p.Hkv, n0 = ktile * 128;
+    const int G = p.Hq / p.Hkv;
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* dKb = p.dk + b * p.sdk.b + hkv * p.sdk.h;
+    bf16_t* dVb = p.dv + b * p.sdv.b + hkv * p.sdv.h;
+    const int key = n0 + w * 32 + r;
+    const bool kmem = key < p.Sk, kval = key < kvl;
+    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
+        Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        pin_loaded(Kf[ks]);
+        pin_loaded(Vf[ks]);
+    }
+    f32x16 dK[DT], dV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dK[dt][i] = 0.f;
+            dV[dt][i] = 0.f;
+        }
+    const float sc = p.scale * kLog2e;
+    const int nqt = (p.Sq + BQ - 1) / BQ;
+    const int niter = (n0 < kvl) ? G * nqt : 0;
+    const int per_split = (niter + p.nsplit - 1) / p.nsplit;
+    const int it0 = split * per_split, it1 = min(niter, it0 + per_split);
+    const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s;
+    auto stage = [&](int it, int buf) {  // this wave's share of tile `it` (nothing real past the end): Q, dO, one 4-byte DMA
+        const bool live = it < it1;
+        const int itc = live ? it : it0;
+        const int gq = itc / nqt, t = itc % nqt;
+        const int hq = hkv * G + gq;
+        const bf16_t* Qh_ = p.q + b * p.sq.b + hq * p.sq.h;
+        const bf16_t* dOh_ = p.dout + b * p.sdo.b + hq * p.sdo.h;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
+        char* base = smem + buf * BUFB;
+        const int lim = live ? p.Sq : 0;
+        Stage::issue(rq, base, t * BQ, lim, qs_s);
+        Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
+        const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
+        char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
+        dma4(rs, sdst, (live && w < 2) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+    };
+    if (it0 < it1) stage(it0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int rbase = r * RB + ((h ^ swz_f<RB>(r)) << 4);
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int tbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 4 * h + (i16 >> 2) + 8 * hi;
+        tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;
+    }
+    int buf = 0;
+    for (int it = it0; it < it1; ++it) {
+        const char* Qs = smem + buf * BUFB;
+        const char* dOs = Qs + TILE;
+        const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE);
+        const float* dl_s = lse_s + 64;
+        stage(it + 1, buf ^ 1);  // the other buffer: every wave left it at the barrier that ended tile it-1
+        // lane-constant addresses, made opaque per use site: hoisted out of the loop their XOR-ed variants (6 row + 6 transposed
+        // addresses) stay live across it — and this kernel has no register to spare (a spill inside the loop is a scratch load,
+        // i.e. a vmcnt(0) that drains the DMA)
+        int rb = rbase, tb0 = tbase[0], tb1 = tbase[1];
+        auto rowoff = [&](int ks) { return (rb ^ ((ks & 7) << 5)) + (ks >> 3) * 256; };
+        auto trfrag = [&](const char* tile, int dt) {  // 32 columns 32 dt.., 16 rows from `tile`
+            const int x = (dt & 3) << 6;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (dt >> 2) * 256 + (tb0 ^ x)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (dt >> 2) * 256 + (tb1 ^ x)));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        bf16x8 qa[KS], da[KS], ta[2 * DT], tc[2 * DT];
+        auto read_rows = [&](int qt) {
+            const char* Qq = Qs + qt * 32 * RB;
+            const char* dOq = dOs + qt * 32 * RB;
+            asm volatile("" : "+v"(rb));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qa[ks] = *reinterpret_cast<const bf16x8*>(Qq + rowoff(ks));
+                da[ks] = *reinterpret_cast<const bf16x8*>(dOq + rowoff(ks));
+            }
+        };
+        read_rows(0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const char* Qq = Qs + qt * 32 * RB;
+            const char* dOq = dOs + qt * 32 * RB;
+            f32x16 S, dP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[i] = 0.f;
+                dP[i] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {  // M1
+                S = mfma32(qa[ks], Kf[ks], S);
+                dP = mfma32(da[ks], Vf[ks], dP);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (T strictly behind M1: its registers are the row fragments')
+            asm volatile("" : "+v"(tb0), "+v"(tb1));
+#pragma unroll
+            for (int st = 0; st < 2 * DT; ++st) {  // T: in flight while the softmax runs
+                ta[st] = trfrag(dOq + (st & 1) * 16 * RB, st >> 1);
+                tc[st] = trfrag(Qq + (st & 1) * 16 * RB, st >> 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {  // V
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
+                    if (!kval) pv = 0.f;
+                    S[4 * g4 + i] = pv;
+                    dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
+                }
+            }
+            bf16x8 Pf[2], dSf[2];
+            Pf[0] = pack8(S, 0);
+            Pf[1] = pack8(S, 1);
+            dSf[0] = pack8(dP, 0);
+            dSf[1] = pack8(dP, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 2 * DT; ++st) {  // M2
+                dV[st >> 1] = mfma32(ta[st], Pf[st & 1], dV[st >> 1]);
+                dK[st >> 1] = mfma32(tc[st], dSf[st & 1], dK[st >> 1]);
+            }
+            // (issued behind the MFMAs, not before them: at head_dim 96 row + transposed fragments together do not fit the 256
+            // registers of two waves per SIMD; the reads overlap the matrix pipe's drain and the other workgroup's wave)
+            if (qt + 1 < QT) read_rows(qt + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile it+1 has landed; this wave's reads of tile it are done
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.nsplit > 1) {
+        if (kmem) {
+            const int64_t plane = (int64_t)p.B * p.Hkv * p.Sk * D;
+            float* wk = p.split_ws + (((int64_t)split * p.B * p.Hkv + bh) * p.Sk + key) * D;
+            float* wv = wk + (int64_t)p.nsplit * plane;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = dt * 32 + 8 * e + 4 * h;
+                    f32x4 a, c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = dK[dt][4 * e + i];
+                        c[i] = dV[dt][4 * e + i];
+                    }
+                    *reinterpret_cast<f32x4*>(wk + d) = a;
+                    *reinterpret_cast<f32x4*>(wv + d) = c;
+                }
+        }
+        return;
+    }
+    if (kmem) {
+        const float s_ = p.scale;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = dt * 32 + 8 * e + 4 * h;
+                store4(dKb + (int64_t)key * p.sdk.s + d, dK[dt][4 * e] * s_, dK[dt][4 * e + 1] * s_, dK[dt][4 * e + 2] * s_,
+                       dK[dt][4 * e + 3] * s_);
+                store4(dVb + (int64_t)key * p.sdv.s + d, dV[dt][4 * e], dV[dt][4 * e + 1], dV[dt][4 * e + 2], dV[dt][4 * e + 3]);
+            }
+    }
+}
+
+// =============================================================================================
 // backward in ONE pass (head_dim 64): dQ, dK and dV from a single sweep — five MFMA products per (query, key) block
 // instead of the seven of the dq + dkdv pair (S and dP are formed once), and one softmax / dS evaluation instead of two.
 //
@@ -2519,6 +2751,23 @@ int launch_bwd(const AttnParams& p, hipStream_t st) {
             }
             dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
             hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<D>), grid, dim3(512), lds, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
+        }
+        if (p.nsplit > 1) {
+            const int64_t n = (int64_t)p.B * p.Hkv * p.Sk * (D / 4);
+            hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(split reduce)");
+        }
+    } else if (D == 96 && variant == 0) {
+        if constexpr (D == 96) {
+            constexpr size_t lds = 2 * (2 * 64 * 256 + 512) + 4 * 256;  // two Q | dO | stats buffers (256-byte rows) + filler slots
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv4_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
+            hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<D>), grid, dim3(256), lds, st, p);
             VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv)");
         }
         if (p.nsplit > 1) {
