@@ -59,9 +59,11 @@ int vft_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
  * allocate vft_attn_bwd_workspace(...) floats to let (a) head_dim 64 with Sk > 128 run the ONE-PASS backward (dQ, dK
  * and dV from a single sweep: five matrix products per block instead of seven; the workgroup that walks a (batch, head)
  * pair's key blocks keeps the running dQ in an fp32 plane of the scratch — B*Hq*ceil(Sq/64)*64*D floats per key-range
- * slice) and (b) short key sequences (cross-attention, Sk = 77: sdxl/denoiser.py:224-262) split their query tiles over
- * more workgroups — the partial dK/dV are then summed in a fixed order.  With less scratch the dq + dkdv kernel pair
- * runs.  dk/dv are per kv head (the sum over the query heads of a GQA group happens in-kernel).  Deterministic (no
+ * slice), (b) head_dim 128 / 256 without a key mask (AuraFlow; Sq a multiple of 8, at least 512 queries and keys) run
+ * the STORED-dS backward: the dK/dV kernel writes dS^T (bf16, B*Hq*Sk*roundup(Sq,32) elements of the scratch) and dQ is one
+ * batched GEMM on the weight-gradient kernel — again five products instead of seven — and (c) short key sequences
+ * (cross-attention, Sk = 77: sdxl/denoiser.py:224-262) split their query tiles over more workgroups — the partial dK/dV
+ * are then summed in a fixed order.  With less scratch the dq + dkdv kernel pair runs.  dk/dv are per kv head (the sum over the query heads of a GQA group happens in-kernel).  Deterministic (no
  * atomics, fixed summation order). */
 int64_t vft_attn_bwd_workspace(int B, int Hq, int Hkv, int Sq, int Sk, int D);
 int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
@@ -73,7 +75,7 @@ int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  void* stream);
 /* Tuning / A-B control of the attention kernels (process-wide; the trainers never call it): 0 = automatic, 1 = the
  * first-generation 4-wave kernels for every head_dim, 2 = the 8-wave dK/dV kernel for head_dim >= 128, 3 = the dq + dkdv
- * kernel pair where the one-pass backward would run. */
+ * kernel pair where the one-pass / stored-dS backward would run. */
 int vft_attn_variant(int variant);
 
 /* ---- LoRA -----------------------------------------------------------------------------------

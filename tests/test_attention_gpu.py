@@ -160,3 +160,36 @@ def test_attention_one_pass_backward(gpu, B, Hq, Hkv, Sq, Sk, kv_len):
         assert torch.equal(a, b_)  # fixed summation order: reproducible
     for a, c in zip(runs[0], runs[2]):  # the two forms agree to bf16 rounding of differently ordered fp32 sums
         assert _rel(a, c) < 6e-3, _rel(a, c)
+
+
+@pytest.mark.parametrize(
+    "B,Hq,Hkv,Sq,Sk,D,layout",
+    [
+        (1, 12, 12, 1160, 1160, 256, "bshd"),  # AuraFlow: q / k / v as (B, S, H, D) memory
+        (2, 4, 2, 520, 600, 128, "bhsd"),      # GQA (two query heads share K), Sq != Sk, a last tile of 8 queries
+        (1, 2, 2, 2056, 512, 256, "bhsd"),     # few key blocks: the dK/dV kernel splits its query tiles, 9 row tiles in the dQ GEMM
+    ],
+)
+def test_attention_stored_ds_backward(gpu, B, Hq, Hkv, Sq, Sk, D, layout):
+    """head_dim >= 128 without a key mask (Sq a multiple of 8, >= 512 queries and keys): the dK/dV kernel writes dS^T and dQ is
+    one batched GEMM on the weight-gradient kernel (vft_attn_bwd in include/vft_hip.h).  Against the oracle, bit-identical
+    on a second run, and against the dq + dkdv pair (variant 3)."""
+    from vision_ft_amd import kernels
+
+    _run_case(gpu, B, Hq, Hkv, Sq, Sk, D, layout=layout, seed=Sq + D)
+    g = torch.Generator().manual_seed(11)
+    q, do = (torch.randn(B, Hq, Sq, D, generator=g).to(torch.bfloat16).to(gpu) for _ in range(2))
+    k, v = (torch.randn(B, Hkv, Sk, D, generator=g).to(torch.bfloat16).to(gpu) for _ in range(2))
+    runs = []
+    for variant in (0, 0, 3):
+        assert kernels._C.lib().vft_attn_variant(variant) == 0
+        try:
+            qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+            kernels.flash_attention(qq, kk, vv).backward(do)
+            runs.append((qq.grad, kk.grad, vv.grad))
+        finally:
+            kernels._C.lib().vft_attn_variant(0)
+    for a, b_ in zip(runs[0], runs[1]):
+        assert torch.equal(a, b_)
+    for a, c in zip(runs[0], runs[2]):
+        assert _rel(a, c) < 6e-3, _rel(a, c)

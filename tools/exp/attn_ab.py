@@ -1,6 +1,6 @@
 """A/B timing of the attention kernels on one GPU, one process (box-to-box variance rules out comparisons across calls):
 forward and backward at the bench shapes, `vft_attn_variant` 0 (automatic: one-pass backward at head_dim 64) against 3
-(the dq + dkdv pair), HIP events around each call, median of `reps` after a warm-up.  Prints algorithmic TFLOP/s
+(the dq + dkdv pair; at head_dim >= 128 variant 0 is the stored-dS form), HIP events around each call, median of `reps` after a warm-up.  Prints algorithmic TFLOP/s
 (4 B H Sq Sk D forward, 10 B H Sq Sk D backward).
 
     python tools/exp/attn_ab.py [sdxl|aura|lumina|all] [reps]"""
@@ -25,28 +25,33 @@ def bf(*s):
     return torch.randn(*s, device=dev, dtype=torch.float32).to(torch.bfloat16)
 
 
-def time_case(B, Hq, Hkv, Sq, Sk, D, variant, reps):
-    _C.check(_C.lib().vft_attn_variant(variant), "vft_attn_variant")
+def time_case(B, Hq, Hkv, Sq, Sk, D, variants, reps):
+    """Median forward / backward ms per variant; the variants alternate inside every repetition (run one after the other,
+    the first would be measured on a colder / differently clocked chip: the same forward kernel read 5 % apart that way)."""
+    q = bf(B, Sq, Hq, D).permute(0, 2, 1, 3).requires_grad_(True)
+    k, v = (bf(B, Sk, Hkv, D).permute(0, 2, 1, 3).requires_grad_(True) for _ in range(2))
+    do = bf(B, Sq, Hq, D).permute(0, 2, 1, 3)
+    times = {}
     try:
-        q = bf(B, Sq, Hq, D).permute(0, 2, 1, 3).requires_grad_(True)
-        k, v = (bf(B, Sk, Hkv, D).permute(0, 2, 1, 3).requires_grad_(True) for _ in range(2))
-        do = bf(B, Sq, Hq, D).permute(0, 2, 1, 3)
-        fwd, bwd = [], []
         for i in range(reps + 2):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record()
-            o = kernels.flash_attention(q, k, v)
-            e[1].record()
-            o.backward(do)
-            e[2].record()
-            torch.cuda.synchronize()
-            q.grad = k.grad = v.grad = None
-            if i >= 2:
-                fwd.append(e[0].elapsed_time(e[1]))
-                bwd.append(e[1].elapsed_time(e[2]))
-        return statistics.median(fwd), statistics.median(bwd)
+            for variant in variants:
+                if _C.lib().vft_attn_variant(variant) != 0:  # an older library (VFT_LIB_PATH) without this variant
+                    continue
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                o = kernels.flash_attention(q, k, v)
+                e[1].record()
+                o.backward(do)
+                e[2].record()
+                torch.cuda.synchronize()
+                q.grad = k.grad = v.grad = None
+                if i >= 2:
+                    f, b_ = times.setdefault(variant, ([], []))
+                    f.append(e[0].elapsed_time(e[1]))
+                    b_.append(e[1].elapsed_time(e[2]))
     finally:
         _C.lib().vft_attn_variant(0)
+    return {var: (statistics.median(f), statistics.median(b_)) for var, (f, b_) in times.items()}
 
 
 def main():
@@ -58,11 +63,7 @@ def main():
         for (B, Hq, Hkv, Sq, Sk, D) in shapes:
             unit = B * Hq * Sq * Sk * D / 1e9
             row = f"{name:7s} B{B} Hq{Hq} Hkv{Hkv} Sq{Sq} Sk{Sk} D{D}:"
-            for variant in ((0, 3) if D == 64 else (0,)):
-                try:
-                    f, b_ = time_case(B, Hq, Hkv, Sq, Sk, D, variant, reps)
-                except ValueError:  # an older library (VFT_LIB_PATH) without this variant
-                    continue
+            for variant, (f, b_) in time_case(B, Hq, Hkv, Sq, Sk, D, (0, 3) if D != 96 else (0,), reps).items():
                 row += f"  [variant {variant}] fwd {f:7.3f} ms {4 * unit / f:7.1f} TF/s | bwd {b_:7.3f} ms {10 * unit / b_:7.1f} TF/s"
             print(row, flush=True)
 

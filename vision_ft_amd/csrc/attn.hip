@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "vft_common.h"
+#include "wgrad8.h"
 
 namespace {
 
@@ -51,6 +52,9 @@ struct AttnParams {
     float* nlse;            // one-pass backward: [B, Hq, Sq] -lse / scale (the S accumulators start from it)
     const int32_t* kv_len;  // [B] or nullptr
     float* split_ws;        // bwd, nsplit > 1: fp32 partial dK | dV, each [nsplit][B*Hkv][Sk][D]
+    bf16_t* ds_t;           // bwd, head_dim >= 128 stored-dS form: dS^T [B*Hq][Sk][ds_ld] written by the dK/dV kernel, else null
+    int64_t ds_ld;
+    float* dq_ws;           // stored-dS form: fp32 partial tiles of the batched dQ GEMM
     int nsplit;
     int B, Hq, Hkv, Sq, Sk;
     float scale;
@@ -450,6 +454,34 @@ struct DmaTile {
             for (int q = 0; q < NI; ++q)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds_tile + (wv * NI + q) * 1024), 16, voffs[q], 0, 0, 0);
         }
+    }
+};
+
+// The same tile image with NOTHING recomputed per tile on the vector ALU but one xor + one add per piece: the descriptor's
+// base is moved to the tile's first row (scalar arithmetic) and its extent ends with the tensor, so rows past the end fail
+// the hardware range check by themselves; the lane keeps its row offset (lane_row() * row stride) and its swizzled chunk of
+// piece 0 — piece q's row is RPI * q further down and its swizzle differs from piece 0's by a compile-time constant
+// (no carries between the lane / wave bits and q's bits of the row number, checked below).  For the one-wave-per-SIMD
+// kernels (head_dim >= 128) where every vector instruction of the staging code is exposed.
+constexpr int swz_rows_const(int RB, int row) { return RB == 128 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3)); }
+template <int D, int ROWS, int NW>
+struct DmaTileRel {
+    static constexpr int RB = D * 2, NI = ROWS * RB / 1024 / NW, RPI = 1024 / RB;
+    static_assert(RB % 256 == 0 && NI >= 1 && NI * RPI <= 8 && (NI * RPI & (NI * RPI - 1)) == 0, "piece rows must stay below the wave's row bits");
+    static __device__ __forceinline__ int lane_row() {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        return wv * NI * RPI + (lane * 16) / RB;
+    }
+    static __device__ __forceinline__ int lane_chunk_bytes() {
+        const int lane = threadIdx.x & 63, slot = ((lane * 16) % RB) >> 4;
+        return ((slot & ~15) | ((slot & 15) ^ swz_f<RB>(lane_row()))) << 4;
+    }
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs_tile, char* lds_tile, int lane_row_bytes, int lane_chunk, int stride_bytes) {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        int voffs[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) voffs[q] = lane_row_bytes + q * RPI * stride_bytes + (lane_chunk ^ (swz_rows_const(RB, q * RPI) << 4));
+        dma16_group<NI>(rs_tile, lds_tile + wv * NI * 1024, voffs);
     }
 };
 
@@ -1623,9 +1655,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv2_kernel(AttnParams p) {
 // buffers filled three tiles ahead; tiles past the end are issued as all-out-of-range DMAs (zeros, no memory traffic) so
 // that the counted vmcnt is the same in every iteration.  One barrier per tile.
 // =============================================================================================
-template <int D, int BQ>
+template <int D, int BQ, bool STORE_DS = false>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(AttnParams p) {
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, NB = 4, QT = BQ / 32;
+    constexpr int NST = STORE_DS ? 2 * QT : 0;  // 16-byte dS^T stores per lane and tile (always issued: out-of-range ones are dropped)
+    static_assert(!STORE_DS || D >= 128, "stored dS: head_dim >= 128");
     static_assert(BQ == 32 || BQ == 64, "query tile");
     constexpr int TILE = BQ * RB;           // bytes of one Q (or dO) tile
     constexpr int BUFB = 2 * TILE + 512;    // Q | dO | lse[BQ] | delta[BQ]  (256-byte slots: one 4-byte DMA each)
@@ -1680,28 +1714,63 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
     const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s;
     // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's BQ lse
     // values, wave 1 its delta values, waves 2-3 a filler, so that every wave issues NDMA instructions per tile
+    // (query head of the kv group, query tile) of the tile staged next: advanced by hand — one wave per SIMD hides nothing,
+    // and a scalar division per tile is ~20 dependent instructions in the open
+    int sg = it0 / nqt, stl = it0 - sg * nqt;
+    typedef DmaTileRel<(D >= 128 ? D : 128), (D >= 128 ? BQ : 32), 4> StageRel;
+    // this lane's part of every DMA address (see DmaTileRel): row offset under either row stride, swizzled chunk, stats slot
+    int lrow_q = StageRel::lane_row() * qs_s * 2, lrow_do = StageRel::lane_row() * dos_s * 2, lchunk = StageRel::lane_chunk_bytes();
+    int lstat = lane < BQ ? lane * 4 : (int)0x80000000u;
+    if constexpr (D >= 128) {
+        pin_loaded(lrow_q);
+        pin_loaded(lrow_do);
+        pin_loaded(lchunk);
+        pin_loaded(lstat);
+    }
     auto stage = [&](int it, int buf) {
         const bool live = it < it1;
-        const int itc = live ? it : it0;
-        const int gq = itc / nqt, t = itc % nqt;
+        const int gq = live ? sg : 0, t = live ? stl : 0;
         const int hq = hkv * G + gq;
         const bf16_t* Qh_ = p.q + b * p.sq.b + hq * p.sq.h;
         const bf16_t* dOh_ = p.dout + b * p.sdo.b + hq * p.sdo.h;
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
         char* base = smem + buf * BUFB;
-        const int lim = live ? p.Sq : 0;
-        Stage::issue(rq, base, t * BQ, lim, qs_s);
-        Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
         const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
-        if constexpr (VFT_ATTN_BWD_ASM_DMA != 0 || D >= 128) dma4(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
-        else dma4_builtin(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        if constexpr (D >= 128) {
+            // descriptors that start at the tile's first row and end with the head's rows (a dead tile: no bytes at all)
+            const int row0 = t * BQ;
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(Qh_ + (int64_t)row0 * p.sq.s), 0, live ? (int)(((int64_t)(p.Sq - 1 - row0) * p.sq.s + D) * 2) : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)(dOh_ + (int64_t)row0 * p.sdo.s), 0, live ? (int)(((int64_t)(p.Sq - 1 - row0) * p.sdo.s + D) * 2) : 0, 0x00020000);
+            StageRel::issue(rq, base, lrow_q, lchunk, qs_s * 2);
+            StageRel::issue(rdo, base + TILE, lrow_do, lchunk, dos_s * 2);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow + row0), 0, (live && w < 2) ? (p.Sq - row0) * 4 : 0, 0x00020000);
+            dma4(rs, sdst, lstat);
+        } else {
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
+            const int lim = live ? p.Sq : 0;
+            Stage::issue(rq, base, t * BQ, lim, qs_s);
+            Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.lse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
+            if constexpr (VFT_ATTN_BWD_ASM_DMA != 0) dma4(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+            else dma4_builtin(rs, sdst, (live && w < 2 && lane < BQ) ? (t * BQ + lane) * 4 : (int)0x80000000u);
+        }
+        if (++stl == nqt) stl = 0, ++sg;
     };
 #pragma unroll
-    for (int j = 0; j < NB - 1; ++j) stage(it0 + j, j);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NDMA) : "memory");  // the first tile has landed
+    for (int j = 0; j < NB - 1; ++j) {
+        stage(it0 + j, j);
+        if constexpr (STORE_DS) {
+            // The loop's counted wait allows the dS stores of two tiles in flight behind the DMAs of tile it+1; NST dropped
+            // (out-of-range) stores here make that count exact from the first iteration on.
+            if (j == NB - 3) {
+                const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc((void*)p.ds_t, 0, 0, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < NST; ++e) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rnull, (int)0x80000000u, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NDMA + NST) : "memory");  // the first tile has landed
     __builtin_amdgcn_s_barrier();
 
     // fragment addresses (bytes inside a 32-row tile): row reads: query row r, chunk 2 ks + h;
@@ -1718,6 +1787,19 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
     constexpr int TF = D >= 256 ? 2 : (2 * DT < 3 ? 2 * DT : 3);  // (d-tile, k-step) steps of transposed fragments in flight
     static_assert(PF <= KS && TF <= 2 * DT, "ring depth");
 
+    // stored dS: (query head, query tile) of the tile being computed, its plane of dS^T, this lane's fixed byte offset in it
+    // (rows of ds_ld = 32 * nqt elements: no query guard; keys past the end are out of range for good)
+    int cg = it0 / nqt, ct = it0 - cg * nqt;
+    __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)p.q, 0, 0, 0x00020000);
+    int ds_voff = (int)0x80000000u;
+    auto ds_plane = [&]() {
+        if constexpr (STORE_DS)
+            rds = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ds_t + ((int64_t)b * p.Hq + hkv * G + cg) * p.Sk * p.ds_ld), 0, (int)((int64_t)p.Sk * p.ds_ld * 2), 0x00020000);
+    };
+    if constexpr (STORE_DS) {
+        ds_plane();
+        if (kmem) ds_voff = (int)(((int64_t)key * p.ds_ld + 8 * h) * 2);
+    }
     int buf = 0;
     for (int it = it0; it < it1; ++it) {
         const char* Qs = smem + buf * BUFB;
@@ -1808,6 +1890,19 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
                         dV[st >> 1] = mfma32(ta[g & 1][j], Pf[st & 1], dV[st >> 1]);
                         dK[st >> 1] = mfma32(tc[g & 1][j], dSf[st & 1], dK[st >> 1]);
                     }
+                    if constexpr (STORE_DS) {
+                        // dS^T[key][q] for the batched dQ GEMM (vft_wg8_batched), in the shadow of this group's MFMAs.  A lane
+                        // holds, of its key, queries 8 g + 4 h + i: swapping the upper half-wave of the even-g registers with the
+                        // lower half-wave of the odd-g ones (v_permlane32_swap) leaves 8 consecutive queries = one 16-byte
+                        // store per lane and 16-query pair.  Lane part of the address fixed, tile part in the scalar offset.
+                        if (g < 2) {
+                            const u32x4 d = __builtin_bit_cast(u32x4, dSf[g]);
+                            const auto x0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                            const auto x1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                            const u32x4 o = {x0[0], x1[0], x0[1], x1[1]};
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rds, ds_voff, (ct * BQ + qt * 32 + 16 * g) * 2, 0);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1876,10 +1971,17 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
                 }
             }
         }
-        // this wave's share of tile it+1 has landed (issued three tiles ago); tiles it+2, it+3 stay in flight
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * NDMA) : "memory");
+        // this wave's share of tile it+1 has landed (issued three tiles ago); tiles it+2, it+3 — and the dS stores of tiles
+        // it-1, it, issued after them — stay in flight (vector memory operations retire in issue order)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * (NDMA + NST)) : "memory");
         __builtin_amdgcn_s_barrier();
         buf = buf == NB - 1 ? 0 : buf + 1;
+        if constexpr (STORE_DS) {
+            if (++ct == nqt) {
+                ct = 0, ++cg;
+                ds_plane();
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of ours may still write LDS when the workgroup ends
     if (p.nsplit > 1) {
@@ -2515,7 +2617,7 @@ __global__ __launch_bounds__(256) void attn_bwd1_reduce_kernel(AttnParams p) {
 
 // Row constants of the one-pass backward: delta[b, h, q] = -sum_d dO * O and nlse = -lse / scale (the initial dP / S
 // accumulators); 8 lanes per query row.  (The dq kernel of the two-kernel form computes its delta on the side.)
-template <int D>
+template <int D, bool ONEPASS = true>  // !ONEPASS: +delta only (the stored-dS form: what the dq kernel used to leave for dK/dV)
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     constexpr int LPR = D / 8;  // lanes per row (16 bytes each)
     const int64_t rows = (int64_t)p.B * p.Hq * p.Sq;
@@ -2534,8 +2636,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 #pragma unroll
     for (int o_ = 1; o_ < LPR; o_ <<= 1) dl += __shfl_xor(dl, o_, 64);
     if (row < rows && c == 0) {
-        p.delta[row] = -dl;
-        p.nlse[row] = -p.lse[row] / p.scale;
+        if constexpr (ONEPASS) {
+            p.delta[row] = -dl;
+            p.nlse[row] = -p.lse[row] / p.scale;
+        } else {
+            p.delta[row] = dl;
+        }
     }
 }
 
@@ -2609,6 +2715,16 @@ __host__ inline int bwd1_slices(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     return best;
 }
 __host__ inline int64_t bwd1_plane_floats(int B, int Hq, int Sq, int D) { return (int64_t)B * Hq * ((Sq + 63) / 64) * (64 * D); }
+
+// Stored-dS backward (head_dim >= 128, no key mask): the dK/dV kernel already computes dS for every (key, query) pair — it
+// writes it out (bf16, transposed) and dQ = scale * dS K becomes one batched GEMM on the weight-gradient kernel instead of a
+// second flash kernel that recomputes S and dP: 5 products per pair instead of 7, for one 2-byte write + read per pair.
+__host__ inline bool stored_ds_applies(int B, int Hq, int Sq, int Sk, int D) {
+    if (D < 128 || g_attn_variant != 0 || Sq % 8 != 0 || Sq < 512 || Sk < 512) return false;
+    return (int64_t)Sk * (Sq + 32) * 2 < ((int64_t)1 << 31) - (1 << 20) && (int64_t)B * Hq * Sk * (Sq + 32) * 2 <= ((int64_t)16 << 30);
+}
+__host__ inline int64_t stored_ds_ld(int Sq) { return (Sq + 31) / 32 * 32; }  // whole 32-query tiles: the kernel's stores need no query guard
+__host__ inline int64_t stored_ds_floats(int B, int Hq, int Sq, int Sk) { return (int64_t)B * Hq * Sk * stored_ds_ld(Sq) / 2; }
 
 template <int D>
 int launch_bwd1(AttnParams p, hipStream_t st) {
@@ -2697,7 +2813,34 @@ int launch_fwd2(const AttnParams& p, hipStream_t st) {
 
 template <int D, int BQ>
 int launch_bwd(const AttnParams& p, hipStream_t st) {
-    const int variant = g_attn_variant == 3 ? 0 : g_attn_variant;  // 3 = "the pair where the one-pass kernel would run": the default pair
+    const int variant = g_attn_variant == 3 ? 0 : g_attn_variant;  // 3 = "the pair where the one-pass / stored-dS forms would run": the default pair
+    if constexpr (D >= 128) {
+        if (p.ds_t != nullptr) {
+            constexpr int BQ3 = 32;
+            constexpr size_t lds = 4 * (2 * BQ3 * D * 2 + 512) + 4 * 256;
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv3_kernel<D, BQ3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            const int64_t rows = (int64_t)p.B * p.Hq * p.Sq * (D / 8);
+            hipLaunchKernelGGL((attn_delta_kernel<D, false>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
+            dim3 grid(xcd_grid(((p.Sk + 127) / 128) * p.nsplit, p.B * p.Hkv));
+            hipLaunchKernelGGL((attn_bwd_dkdv3_kernel<D, BQ3, true>), grid, dim3(256), lds, st, p);
+            VFT_CHECK_LAUNCH("vft_attn_bwd(dkdv + dS)");
+            if (p.nsplit > 1) {
+                const int64_t n = (int64_t)p.B * p.Hkv * p.Sk * (D / 4);
+                hipLaunchKernelGGL(attn_bwd_split_reduce_kernel<D>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+                VFT_CHECK_LAUNCH("vft_attn_bwd(split reduce)");
+            }
+            Wg8Batch bt{};
+            bt.nbatch = p.B * p.Hq, bt.inner = p.Hq, bt.G = p.Hq / p.Hkv;
+            bt.a_bstride = (int64_t)p.Sk * p.ds_ld, bt.b_outer = p.sk.b, bt.b_inner = p.sk.h, bt.o_outer = p.sdq.b, bt.o_inner = p.sdq.h;
+            bt.scale = p.scale;
+            return vft_wg8_batched(p.ds_t, p.k, p.dq, p.dq_ws, p.Sk, p.Sq, D, p.ds_ld, p.sk.s, p.sdq.s, bt, st);
+        }
+    }
     if (D != 96 && variant != 1) {
         if constexpr (D != 96) {
             constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t);  // double-buffered K | V tiles, unpadded
@@ -2838,7 +2981,10 @@ extern "C" int64_t vft_attn_bwd_workspace(int B, int Hq, int Hkv, int Sq, int Sk
     const int n1 = bwd1_slices(B, Hq, Hkv, Sq, Sk, D);
     if (n1 > 0) return 2 * delta_floats + (int64_t)n1 * bwd1_plane_floats(B, Hq, Sq, D);  // -delta, -lse/scale, running-dQ plane(s)
     const int ns = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
-    return delta_floats + (ns > 1 ? 2 * (int64_t)ns * B * Hkv * Sk * D : 0);
+    const int64_t base = delta_floats + (ns > 1 ? 2 * (int64_t)ns * B * Hkv * Sk * D : 0);
+    if (stored_ds_applies(B, Hq, Sq, Sk, D))  // + dS^T (bf16) and the dQ GEMM's partial tiles
+        return base + stored_ds_floats(B, Hq, Sq, Sk) + vft_wg8_batched_scratch_floats(Sk, Sq, D, B * Hq);
+    return base;
 }
 
 extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
@@ -2886,6 +3032,14 @@ extern "C" int vft_attn_bwd(const void* q, const void* k, const void* v, const v
     }
     p.nsplit = dkdv_nsplit(B, Hq, Hkv, Sq, Sk, D);
     if (p.nsplit > 1 && ws_floats < delta_floats + 2 * (int64_t)p.nsplit * B * Hkv * Sk * D) p.nsplit = 1;
+    if (kv_len == nullptr && stored_ds_applies(B, Hq, Sq, Sk, D)) {
+        const int64_t base = delta_floats + (p.nsplit > 1 ? 2 * (int64_t)p.nsplit * B * Hkv * Sk * D : 0);
+        if (ws_floats >= base + stored_ds_floats(B, Hq, Sq, Sk) + vft_wg8_batched_scratch_floats(Sk, Sq, D, B * Hq)) {
+            p.ds_t = reinterpret_cast<bf16_t*>(delta_ws + base);
+            p.ds_ld = stored_ds_ld(Sq);
+            p.dq_ws = delta_ws + base + stored_ds_floats(B, Hq, Sq, Sk);
+        }
+    }
     switch (D) {
         case 64: return launch_bwd<64, 64>(p, st);
         case 96: return launch_bwd<96, 64>(p, st);

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "vft_common.h"
+#include "wgrad8.h"
 
 namespace {
 
@@ -76,6 +77,14 @@ struct Wg8Params {
     int a_bytes, b_bytes;  // extents for the buffer descriptors (< 2^31)
     int slices;
     int cH, cW, cC;  // CONV: image height / width / input channels (Cc = 9 * cC)
+    // batched mode (nbatch > 1; attention's dQ = dS^T-transposed x K per (batch, head), see vft_wg8_batched): operand bases of
+    // batch bi = (bo, bi_in) with bo = bi / inner, bi_in = bi % inner:  a + bi * a_bs,  b + bo * b_os + (bi_in / G) * b_is
+    int nbatch, inner, G;
+    int64_t a_bs, b_os, b_is;
+    // batched mode with ONE slice: the scaled bf16 result straight from the accumulators (no partial tiles, no reduce pass)
+    bf16_t* direct;
+    int64_t ldo, o_os, o_is;
+    float oscale;
 };
 
 template <bool CONV>
@@ -89,24 +98,26 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     //      straddles a convolution tap (each tap's Cin is rounded up to whole halves; the overhang reads zeros)
     const int hpt = ((CONV ? p.cC : p.Cc) + 127) / 128, nhalves = (CONV ? 9 : 1) * hpt;
     const int tiles_r = (p.R + BM - 1) / BM, tiles_c = (nhalves + 1) / 2, ntiles = tiles_r * tiles_c;
-    const int nitems = ntiles * p.slices, nkt_all = (p.M + 63) / 64;
-    int r0, h0, kt0, nkt, slice;
+    const int nitems = ntiles * p.nbatch * p.slices, nkt_all = (p.M + 63) / 64;
+    int r0, h0, kt0, nkt, slice, batch;
     // id -> item: XCD-contiguous (workgroup ids go round-robin over the 8 XCDs and the grid is a multiple of 8 or a single
     // round, so vt & 7 labels the XCD): one XCD takes whole slices, whose tiles share their dy / x column blocks through
     // that XCD's L2 (measured: FETCH_SIZE of the 1280 x 1280 x 16384 problem 420 MB with round-robin items)
     auto decode = [&](int vt) {
         const int xcd = vt & 7, q = nitems >> 3, rr = nitems & 7;
         const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vt >> 3);
-        slice = lin / ntiles;
-        const int tile = lin - slice * ntiles;
+        slice = lin / (ntiles * p.nbatch);
+        const int rem = lin - slice * ntiles * p.nbatch;
+        batch = rem / ntiles;
+        const int tile = rem - batch * ntiles;
         r0 = (tile / tiles_c) * BM;
         h0 = (tile % tiles_c) * 2;
         kt0 = (int)((int64_t)slice * nkt_all / p.slices);
         nkt = (int)((int64_t)(slice + 1) * nkt_all / p.slices) - kt0;
     };
 
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.b_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.b_bytes, 0x00020000);
     const int stepa = (int)(64 * p.lda * 2), stepb = (int)(64 * p.ldb * 2);  // bytes per reduction tile
 
     // ---- LDS-DMA sources.  One instruction = 4 rows x 256 B: lane -> (row = lane >> 4, slot = lane & 15); the slot holds
@@ -119,6 +130,11 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     const int q64 = CONV ? 64 / p.cW : 0, r64 = CONV ? 64 % p.cW : 0;
     const int lrow = lane >> 4;
     auto setup = [&]() {
+        if (p.nbatch > 1) {  // this item's operands (wave-uniform: scalar descriptor rebuild)
+            const int bo = batch / p.inner, bin = batch - bo * p.inner;
+            ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (int64_t)batch * p.a_bs), 0, p.a_bytes, 0x00020000);
+            rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + (int64_t)bo * p.b_os + (int64_t)(bin / p.G) * p.b_is), 0, p.b_bytes, 0x00020000);
+        }
         if (CONV) {
             const int m0 = kt0 * 64 + 8 * wv, pix = m0 % (p.cH * p.cW);
             s_oh = __builtin_amdgcn_readfirstlane(pix / p.cW);
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
         if (grp == 0) bar();  // both groups are past their last fragment reads: the buffers are free
 
         // ---- the next item's first DMAs fly while this item's partial tile is written out ----------------------
-        const int cr0 = r0, ch0 = h0, cslice = slice;
+        const int cr0 = r0, ch0 = h0, cslice = slice, cbatch = batch;
         const int vn = vt + gridDim.x;
         const bool more = vn < nitems;
         if (more) {
@@ -306,7 +322,12 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
         int etid = tid;  // tail addresses must not stay live across the main loop (see linear8.hip)
         asm volatile("" : "+v"(etid));
         const int el15 = etid & 15, elq = (etid & 63) >> 4;
-        float* const out = p.part + (int64_t)cslice * p.R * p.Cc;
+        float* const out = p.part + ((int64_t)cslice * p.nbatch + cbatch) * p.R * p.Cc;
+        bf16_t* dout = nullptr;
+        if (!CONV && p.direct) {
+            const int bo = cbatch / p.inner;
+            dout = p.direct + (int64_t)bo * p.o_os + (int64_t)(cbatch - bo * p.inner) * p.o_is;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int h = ch0 + b;
@@ -321,8 +342,16 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
 #pragma unroll
                     for (int i = 0; i < FX; ++i) {
                         const int row = cr0 + a * 128 + wr * 64 + i * 16 + el15;
-                        if (cok && row < p.R)
-                            *reinterpret_cast<f32x4*>(out + (int64_t)row * p.Cc + cbase + within) = acc[a][i][b][j];
+                        if (cok && row < p.R) {
+                            if (!CONV && dout) {
+                                bf16x4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[a][i][b][j][e] * p.oscale);
+                                *reinterpret_cast<bf16x4*>(dout + (int64_t)row * p.ldo + cbase + within) = v;
+                            } else {
+                                *reinterpret_cast<f32x4*>(out + (int64_t)row * p.Cc + cbase + within) = acc[a][i][b][j];
+                            }
+                        }
                     }
             }
         }
@@ -372,6 +401,33 @@ __global__ __launch_bounds__(256) void wg8_reduce_kernel(Wg8Reduce p) {
     }
 }
 
+// Batched form of the reduce pass: out[bi][row][col] (bf16, strided per batch) = scale * sum over slices of part[s][bi][row][col]
+struct Wg8ReduceB {
+    const float* part;
+    bf16_t* out;
+    int64_t n;       // R * Cc
+    int Cc, slices, nbatch, inner;
+    int64_t ldo, o_os, o_is;
+    float scale;
+};
+__global__ __launch_bounds__(256) void wg8_reduce_batched_kernel(Wg8ReduceB p) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int bi = blockIdx.y;
+    if (i >= p.n) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(p.part + (int64_t)bi * p.n + i);
+    for (int k = 1; k < p.slices; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.part + ((int64_t)k * p.nbatch + bi) * p.n + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += t[e];
+    }
+    const int64_t row = i / p.Cc, col = i - row * p.Cc;
+    const int bo = bi / p.inner, bin = bi - bo * p.inner;
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(s[e] * p.scale);
+    *reinterpret_cast<bf16x4*>(p.out + (int64_t)bo * p.o_os + (int64_t)bin * p.o_is + row * p.ldo + col) = v;
+}
+
 // Row slices: the count that minimises  rounds x (reduction tiles per slice + fixed per-item cost)  on 256 workgroups
 int pick_slices(int64_t M, int R, int halves) {
     const int ntiles = ((R + BM - 1) / BM) * ((halves + 1) / 2);
@@ -396,7 +452,7 @@ void launch_wg8(const Wg8Params& p, hipStream_t st) {
         attr = true;
     }
     const int hpt = ((CONV ? p.cC : p.Cc) + 127) / 128, nhalves = (CONV ? 9 : 1) * hpt;
-    const unsigned items = (unsigned)(((p.R + BM - 1) / BM) * ((nhalves + 1) / 2) * p.slices);
+    const unsigned items = (unsigned)(((p.R + BM - 1) / BM) * ((nhalves + 1) / 2) * p.slices * p.nbatch);
     const unsigned grid = items < (unsigned)SLOTS ? items : (unsigned)SLOTS;
     hipLaunchKernelGGL(wg8_kernel<CONV>, dim3(grid), dim3(NT), LDS_BYTES, st, p);
 }
@@ -420,6 +476,7 @@ int run_wgrad(const void* dy, const void* x, void* dw, float* scratch, int64_t M
     Wg8Params p{};
     p.a = (const bf16_t*)dy, p.b = (const bf16_t*)x, p.part = scratch, p.M = (int)M, p.R = R, p.Cc = Cc, p.lda = lddy, p.ldb = ldx;
     p.a_bytes = (int)ab, p.b_bytes = (int)bb, p.cH = cH, p.cW = cW, p.cC = cC;
+    p.nbatch = 1, p.inner = 1, p.G = 1;
     const int halves = (conv ? 9 : 1) * (int)((xcols + 127) / 128);
     p.slices = pick_slices(M, R, halves);
     if (conv) launch_wg8<true>(p, (hipStream_t)stream);
@@ -432,6 +489,42 @@ int run_wgrad(const void* dy, const void* x, void* dw, float* scratch, int64_t M
 }
 
 }  // namespace
+
+// ---- internal: batched transposed-A product with a scaled bf16 result (attn.hip: dQ = scale * dS K per (batch, head)) ----
+static int batched_slices(int64_t M, int R, int Cc, int nbatch) {
+    // items = batches x tiles: with many batches one round-robin over the 256 workgroups is balanced without a reduction split
+    const int ntiles = ((R + BM - 1) / BM) * ((((Cc + 127) / 128) + 1) / 2);
+    return (int64_t)ntiles * nbatch >= 2 * SLOTS ? 1 : pick_slices(M, R, (Cc + 127) / 128);
+}
+int64_t vft_wg8_batched_scratch_floats(int64_t M, int R, int Cc, int nbatch) {
+    const int ns = batched_slices(M, R, Cc, nbatch);
+    return ns == 1 ? 4 : (int64_t)ns * nbatch * R * Cc;  // one slice: the result is written directly
+}
+int vft_wg8_batched(const void* a, const void* b, void* out, float* scratch, int64_t M, int R, int Cc, int64_t lda, int64_t ldb,
+                    int64_t ldo, const Wg8Batch& bt, hipStream_t stream) {
+    const char* name = "vft_wg8_batched";
+    VFT_CHECK_ARG(a && b && out && scratch && M > 0 && R > 0 && Cc > 0 && R % 8 == 0 && Cc % 8 == 0 && bt.nbatch > 0 && bt.inner > 0 && bt.G > 0,
+                  "%s: bad arguments", name);
+    VFT_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldo % 4 == 0 && lda >= R && ldb >= Cc && ldo >= Cc, "%s: strides", name);
+    const int64_t ab = ((M - 1) * lda + R) * 2, bb = ((M - 1) * ldb + Cc) * 2;
+    VFT_CHECK_ARG(ab + 130 * lda < (int64_t)1 << 31 && bb + 130 * ldb < (int64_t)1 << 31 && M < (int64_t)1 << 30, "%s: operand beyond 2 GiB", name);
+    Wg8Params p{};
+    p.a = (const bf16_t*)a, p.b = (const bf16_t*)b, p.part = scratch, p.M = (int)M, p.R = R, p.Cc = Cc, p.lda = lda, p.ldb = ldb;
+    p.a_bytes = (int)ab, p.b_bytes = (int)bb;
+    p.nbatch = bt.nbatch, p.inner = bt.inner, p.G = bt.G, p.a_bs = bt.a_bstride, p.b_os = bt.b_outer, p.b_is = bt.b_inner;
+    p.slices = batched_slices(M, R, Cc, bt.nbatch);
+    if (p.slices == 1) {
+        p.direct = (bf16_t*)out, p.ldo = ldo, p.o_os = bt.o_outer, p.o_is = bt.o_inner, p.oscale = bt.scale;
+        launch_wg8<false>(p, stream);
+        return 0;
+    }
+    launch_wg8<false>(p, stream);
+    Wg8ReduceB q{};
+    q.part = scratch, q.out = (bf16_t*)out, q.n = (int64_t)R * Cc, q.Cc = Cc, q.slices = p.slices, q.nbatch = bt.nbatch, q.inner = bt.inner;
+    q.ldo = ldo, q.o_os = bt.o_outer, q.o_is = bt.o_inner, q.scale = bt.scale;
+    hipLaunchKernelGGL(wg8_reduce_batched_kernel, dim3((unsigned)((q.n / 4 + 255) / 256), (unsigned)bt.nbatch), dim3(256), 0, stream, q);
+    return 0;
+}
 
 extern "C" int64_t vft_linear_wgrad_scratch_floats(int64_t M, int R, int Cc) {
     if (M <= 0 || R <= 0 || Cc <= 0) return 0;
