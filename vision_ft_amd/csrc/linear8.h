@@ -21,6 +21,7 @@ struct Lin8Params {
     int64_t ldx, ldw, ldy, ldres;
     int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
     int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
+    int nt_store;          // y is stored with the non-temporal hint (set by vft_lin8_launch: outputs above 16 MiB)
 };
 
 // true when the operands fit the 32-bit offsets of the buffer descriptors (otherwise: first-generation kernel)

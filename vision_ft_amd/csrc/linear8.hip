@@ -28,6 +28,7 @@
 //     reads (conflict-free for the 16x16x32 operand: 16 rows x 4 k-chunks per instruction).
 //   * XCD-aware tile order, epilogue through LDS (full 512-byte row segments), rank extension as one extra MFMA
 //     k-step from registers.
+#include <cstdlib>
 #include <type_traits>
 
 #include "vft_common.h"
@@ -45,6 +46,11 @@ __device__ unsigned long long g_l8_stamps[512][8][12];
 #define L8_STAMP(i) \
     do {            \
     } while (0)
+#endif
+
+// outputs above this size are stored with the non-temporal hint (see the epilogue)
+#ifndef L8_NT_BYTES
+#define L8_NT_BYTES (16ll << 20)
 #endif
 
 namespace {
@@ -437,7 +443,15 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rv[q][e]);
                 }
-                if (m < p.M && n < p.N) *reinterpret_cast<bf16x8*>(p.y + (int64_t)m * p.ldy + n) = v;
+                // Large outputs are written with the non-temporal hint: ordinary stores of a 1 GB result pushed the x / W
+                // tiles the XCD's workgroups share out of its 4 MB L2 (measured, M 98304 N 5120 K 640: 717 -> 637 us;
+                // N 1920: 300 -> 272; M 24576 N 1280 K 5120: 279 -> 259); small outputs stay cacheable for their consumer
+                if (m < p.M && n < p.N) {
+                    bf16x8* dst = reinterpret_cast<bf16x8*>(p.y + (int64_t)m * p.ldy + n);
+                    if (p.nt_store)  // (inline asm: hipcc folds a __builtin_nontemporal_store branch into the plain store)
+                        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+                    else *dst = v;
+                }
             }
             lgk0();
             bar();  // the image is re-used by the next pass
@@ -486,6 +500,12 @@ bool vft_lin8_fits(const Lin8Params& p, bool conv) {
 }
 
 void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
+    static const int64_t nt_bytes = [] {  // VFT_LIN8_NT_MB: A/B knob (outputs above this many MiB are stored non-temporally; -1: never)
+        const char* e = getenv("VFT_LIN8_NT_MB");
+        const int64_t mb = e ? atoll(e) : -2;
+        return mb == -1 ? INT64_MAX : (mb >= 0 ? mb << 20 : (int64_t)L8_NT_BYTES);
+    }();
+    p.nt_store = (int64_t)(p.M - p.m_begin) * p.N * 2 > nt_bytes;
     p.x_bytes = (int)x_extent(p, conv);
     p.w_bytes = (int)w_extent(p);
     if (conv) {
