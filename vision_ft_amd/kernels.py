@@ -1574,6 +1574,13 @@ def linear_fused(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | No
 PLAIN_LINEAR_GEMM = os.environ.get("VFT_PLAIN_LINEAR", "1") != "0"  # A/B switch: 0 = plain nn.Linear stays on the library
 
 
+# Rows below which a frozen projection stays on the library GEMM.  Round 3: 1 — the conditioning MLPs (a handful of rows:
+# the batch) run on the own kernel too: slower by microseconds, but they were the last library GEMMs of a LoRA step, and the
+# library picks other solutions (stream-K, atomics) under graph capture than eagerly: with them gone a captured step computes
+# what the eager step computes.  VFT_LINEAR_MIN_ROWS=1024 restores the round-2 behaviour.
+LINEAR_MIN_ROWS = int(os.environ.get("VFT_LINEAR_MIN_ROWS", "1"))
+
+
 def linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """nn.Linear calls the projection GEMM takes: FROZEN bf16 weights on the GPU (in_features a multiple of 64, out_features
     of 32: the data gradient reduces over out_features and vft_linear_fwd needs K % 32 == 0) and enough rows for the 128-row tiles to matter (tiny conditioning MLPs stay on the library).  Trainable weights
@@ -1581,7 +1588,7 @@ def linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
     images/s there and 26.1 here — the per-step transposes of 2.6 B weights for the data gradient and the table-tuned
     library solutions outweigh the fused bias / skip epilogue."""
     return (PLAIN_LINEAR_GEMM and not weight.requires_grad and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
-            and weight.shape[1] % 64 == 0 and weight.shape[0] % 32 == 0 and x.numel() // x.shape[-1] >= 1024)
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 32 == 0 and x.numel() // x.shape[-1] >= LINEAR_MIN_ROWS)
 
 
 class _Linear(torch.autograd.Function):
