@@ -230,9 +230,9 @@ def test_graph_replay_takes_the_same_steps_as_eager(gpu, tmp_path, accum):
     assert len(l0) == len(l1) == 8
     assert torch.allclose(torch.tensor(l0), torch.tensor(l1), rtol=2e-3, atol=1e-4), (l0, l1)
     # Adam turns last-bit differences into visible weight differences on the zero-initialised lora_up: its first updates are
-    # lr * sign(g), so an element whose tiny gradient changes sign moves by 2 lr.  Graph and eager runs differ in the last
-    # bits of the conditioning MLPs (the library picks other GEMM solutions under capture; its stream-K kernels use atomics)
-    # and in the captured optimizer's device-resident step count / learning rate.  Measured over several runs: eager-vs-eager
-    # 2e-4 .. 4e-3, graph-vs-eager 1.5e-2 .. 5.8e-2 — a wrong gradient scale or a skipped accumulation would give O(1).
+    # lr * sign(g), so an element whose tiny gradient changes sign moves by 2 lr; the captured optimizer also keeps its step
+    # count / learning rate on the device.  Round 2 needed 0.12 here: the conditioning MLPs ran on library GEMMs whose
+    # solutions differ under capture (stream-K, atomics).  Round 3: every projection of the step, those included, runs on
+    # vft_linear_fwd (kernels.LINEAR_MIN_ROWS = 1) — eager-vs-eager noise or 1e-2, whichever is larger.
     noise = dist(u0, u0b)
-    assert dist(u0, u1) < max(3 * noise, 0.12), (dist(u0, u1), noise)
+    assert dist(u0, u1) < max(3 * noise, 1e-2), (dist(u0, u1), noise)
