@@ -53,6 +53,15 @@ __device__ unsigned long long g_l8_stamps[512][8][12];
 #define L8_NT_BYTES (16ll << 20)
 #endif
 
+// experiment: L8_ONE_BAR=1 drops the barrier behind every MFMA burst and the one-barrier stagger of the two wave groups
+// (4 instead of 8 barriers per K-tile: what slot re-use needs; the groups then interleave as the hardware arbitrates)
+#ifndef L8_ONE_BAR
+#define L8_ONE_BAR 0
+#endif
+#ifndef L8_TWO_PHASE
+#define L8_TWO_PHASE 1
+#endif
+
 namespace {
 
 constexpr int NT = 512;
@@ -230,6 +239,34 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     auto tile = [&](int t, auto BUFc, bool has1, bool has2) {
         constexpr int BUF = decltype(BUFc)::value;
         const unsigned char* tb = sm8 + BUF * TILE;
+#if L8_TWO_PHASE
+        // two phases of 32 MFMAs per wave: (X0, W0) + (X0, W1), then (X1, W1) + (X1, W0) — half as many hand-overs between the
+        // two wave groups per K-tile (each costs the barrier's release plus the first operands' latency)
+        read_x(tb, 0);
+        read_w(tb, 0, w0);
+        read_w(tb, 1, w1);
+        if (has1) stage_x(t + 1, BUF ^ 1, 1);
+        lgk0();  // X0 / W0 / W1 slots are re-filled in the next phase
+        bar();
+        mma(acc[0], 0, w0);
+        mma(acc[0], 1, w1);
+        bar();
+        read_x(tb, 1);
+        if (has2) {
+            stage_x(t + 2, BUF, 0);
+            stage_w(t + 2, BUF, 0);
+            stage_w(t + 2, BUF, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        bar();
+        lgk0();
+        mma(acc[1], 1, w1);
+        mma(acc[1], 0, w0);
+        bar();
+        return;
+#endif
         // ---- phase 0: quadrant (X0, W0); re-fills X1 of the other buffer (tile t+1) ----
         read_x(tb, 0);
         read_w(tb, 0, w0);
@@ -237,7 +274,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         lgk0();  // X0's slot is re-filled in the next phase: its reads are done before this rendezvous
         bar();
         mma(acc[0], 0, w0);
-        bar();
+        if (!L8_ONE_BAR) bar();
         // ---- phase 1: (X0, W1); re-fills X0 (tile t+2).  W1's slot is re-filled two phases later, so its reads may
         //      complete behind the rendezvous ----
         read_w(tb, 1, w1);
@@ -245,14 +282,16 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         bar();
         lgk0();
         mma(acc[0], 1, w1);
-        bar();
+        if (!L8_ONE_BAR) bar();
         // ---- phase 2: (X1, W1); re-fills W0 ----
+#ifndef L8_EXP_SKIPREAD  // experiment (wrong results): a third of the fragment reads left out, to see what the LDS pipe costs
         read_x(tb, 1);
+#endif
         if (has2) stage_w(t + 2, BUF, 0);
         bar();
         lgk0();
         mma(acc[1], 1, w1);
-        bar();
+        if (!L8_ONE_BAR) bar();
         // ---- phase 3: (X1, W0 from registers); re-fills W1; everything of tile t+1 has landed after the wait (X0, W0,
         //      W1 of tile t+2 stay in flight) ----
         if (has2) {
@@ -263,7 +302,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         }
         bar();
         mma(acc[1], 0, w0);
-        bar();
+        if (!L8_ONE_BAR) bar();
     };
     // first K-tile complete; X0 / W0 / W1 of the second in flight (its X1 follows in phase 0)
     auto prologue = [&]() {
@@ -313,7 +352,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();
-        if (grp == 1) bar();  // stagger the groups by one barrier
+        if (!L8_ONE_BAR && grp == 1) bar();  // stagger the groups by one barrier
         L8_STAMP(1);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -333,7 +372,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
             }
             if (t < nkt) tile(t, std::integral_constant<int, 0>{}, false, false);
         }
-        if (grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
+        if (!L8_ONE_BAR && grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
         L8_STAMP(2);
 
         // ---- the next tile's first DMAs fly while this tile is written out --------------------------------------
