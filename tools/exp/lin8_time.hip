@@ -1,7 +1,6 @@
 // Diagnostic: time the lin8 GEMM built from the source file given with -DL8_SRC (A/B runs of main-loop variants in one
 // gpurun call).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffast-math -fno-finite-math-only -I vision_ft_amd/csrc
 //   -DL8_SRC='"<path>/linear8.hip"' tools/exp/lin8_time.hip -o tools/exp/lin8_time_<tag>;  run: lin8_time_<tag> cfg M N K [M N K ...]
-// cfg 21 / 22: the NF4 weight modes (vft_lin8_launch_nf4 mode 1 / 2) on random codes
 #include L8_SRC
 
 #include <cstdlib>
@@ -24,27 +23,13 @@ int main(int argc, char** argv) {
         hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
         Lin8Params p{};
         p.x = x, p.w = w, p.y = y, p.M = M, p.N = N, p.K = K, p.ldx = K, p.ldw = K, p.ldy = N;
-        if (cfg > 20) {  // the bf16 weight buffer doubles as packed codes (N*K/2 bytes) and absmax (N*K/64 floats, patched to 1.0f)
-            static const float code[16] = {-1.f, -0.6962f, -0.5251f, -0.3949f, -0.2844f, -0.1848f, -0.0911f, 0.f, 0.0796f, 0.1609f, 0.2461f, 0.3379f, 0.4407f, 0.5626f, 0.723f, 1.f};
-            float *dcode, *dabs;
-            hipMalloc(&dcode, 64), hipMalloc(&dabs, (size_t)N * K / 16);
-            hipMemcpy(dcode, code, 64, hipMemcpyHostToDevice);
-            std::vector<float> ha((size_t)N * K / 64, 0.01f);
-            hipMemcpy(dabs, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
-            p.q_packed = (const uint8_t*)w, p.q_absmax = dabs, p.q_code = dcode;
-            p.QN = cfg == 21 ? N : K, p.QK = cfg == 21 ? K : N;
-        }
-        auto launch = [&]() {
-            if (cfg > 20) vft_lin8_launch_nf4(p, cfg - 20, 0);
-            else vft_lin8_launch(p, cfg, false, 0);
-        };
         hipEvent_t e0, e1;
         hipEventCreate(&e0), hipEventCreate(&e1);
         double best = 1e30;
         for (int round = 0; round < 3; ++round) {
-            for (int i = 0; i < 3; ++i) launch();
+            for (int i = 0; i < 3; ++i) vft_lin8_launch(p, cfg, false, 0);
             hipEventRecord(e0);
-            for (int i = 0; i < 10; ++i) launch();
+            for (int i = 0; i < 10; ++i) vft_lin8_launch(p, cfg, false, 0);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms;

@@ -681,22 +681,9 @@ extern "C" int vft_linear_nf4(const void* x, void* y, const void* bias, const vo
     p.ex = (const bf16_t*)ext_x, p.ew = (const bf16_t*)ext_w;
     p.M = M, p.N = N, p.K = K, p.r = ext_x ? r : 0, p.ldx = ldx, p.ldy = ldy, p.ldres = ldres;
     p.q_packed = (const uint8_t*)packed, p.q_absmax = absmax, p.q_code = code, p.QN = out_features, p.QK = in_features;
-    hipStream_t st = (hipStream_t)stream;
-    {   // second-generation main loop (linear8.hip) with the dequantisation in its W staging; vft_linear_variant(-1) keeps
-        // the first-generation kernel below (A/B), which also takes what the 256-wide NF4 tile does not
-        Lin8Params q{};
-        q.x = p.x, q.y = p.y, q.bias = p.bias, q.res = p.res, q.ex = p.ex, q.ew = p.ew;
-        q.M = M, q.N = N, q.K = K, q.r = p.r, q.ldx = ldx, q.ldy = ldy, q.ldres = ldres;
-        q.q_packed = p.q_packed, q.q_absmax = p.q_absmax, q.q_code = p.q_code, q.QN = out_features, q.QK = in_features;
-        const int mode = transpose_w ? 2 : 1;
-        if (g_variant >= 0 && q.r <= 16 && N >= 256 && vft_lin8_nf4_fits(q, mode)) {
-            vft_lin8_launch_nf4(q, mode, st);
-            VFT_CHECK_LAUNCH("vft_linear_nf4");
-            return 0;
-        }
-    }
     const int rem = N % 256;
     const bool wide = N >= 1024 && (rem == 0 || rem > 192) && (!transpose_w || in_features >= 32);
+    hipStream_t st = (hipStream_t)stream;
     if (!transpose_w) {
         if (wide)
             launch_linear<Cfg<256, 256, 2, 2, 2, false, false, 64, 1>>(p, st);

@@ -22,13 +22,6 @@ struct Lin8Params {
     int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
     int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
     int nt_store;          // y is stored with the non-temporal hint (set by vft_lin8_launch: outputs above 16 MiB)
-    // NF4 weight modes (vft_lin8_launch_nf4): logical weight [QN][QK] row-major in the bitsandbytes packing (element 2i in the
-    // high nibble of byte i), one fp32 absmax per 64 consecutive elements, 16-entry fp32 code table.  Mode 1: y = x . W^T
-    // (N = QN, K = QK); mode 2: y = x . W (N = QK, K = QN: the data gradient).  w / ldw are unused.
-    const uint8_t* q_packed;
-    const float* q_absmax;
-    const float* q_code;
-    int QN, QK;
 };
 
 // true when the operands fit the 32-bit offsets of the buffer descriptors (otherwise: first-generation kernel)
@@ -36,10 +29,6 @@ bool vft_lin8_fits(const Lin8Params& p, bool conv);
 
 // cfg: 1 = 256x256 tile (128 KiB LDS), 2 = 256x128 (96 KiB), 3 = 128x128 (64 KiB, two workgroups per CU).  K % 64 == 0.
 void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st);
-// NF4 weight on the 256x256 tile (mode 1 / 2 above): true when the problem fits (K % 128 == 0 — an even number of K-tiles —
-// feature counts multiples of 64, 32-bit descriptor offsets); otherwise the caller keeps the first-generation kernel
-bool vft_lin8_nf4_fits(const Lin8Params& p, int mode);
-void vft_lin8_launch_nf4(Lin8Params p, int mode, hipStream_t st);
 // tile configuration (1-3, or 11-13 = split launch) with the least modelled time for an (M, N, K) problem on 256 CUs;
 // _plain: among the one-launch configurations 1-3 only (the tail of a split launch)
 int vft_lin8_pick(int M, int N, int K);

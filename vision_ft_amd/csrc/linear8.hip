@@ -53,6 +53,15 @@ __device__ unsigned long long g_l8_stamps[512][8][12];
 #define L8_NT_BYTES (16ll << 20)
 #endif
 
+// experiment: L8_ONE_BAR=1 drops the barrier behind every MFMA burst and the one-barrier stagger of the two wave groups
+// (4 instead of 8 barriers per K-tile: what slot re-use needs; the groups then interleave as the hardware arbitrates)
+#ifndef L8_ONE_BAR
+#define L8_ONE_BAR 0
+#endif
+#ifndef L8_TWO_PHASE
+#define L8_TWO_PHASE 1
+#endif
+
 namespace {
 
 constexpr int NT = 512;
@@ -71,11 +80,9 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int BM_, int BN_, int WAVES_M_, bool CONV_, int WQ_ = 0>
+template <int BM_, int BN_, int WAVES_M_, bool CONV_>
 struct C8 {
     static constexpr bool CONV = CONV_;
-    static constexpr int WQ = WQ_;  // 0: bf16 weight by LDS-DMA; 1: NF4 weight as stored; 2: NF4 weight transposed (data gradient)
-    static_assert(WQ_ == 0 || (BN_ == 256 && !CONV_), "NF4 modes run on the 256-wide tile");
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = 8 / WAVES_M_;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     static constexpr int FX = WM / 32, FW = WN / 32;            // 16-wide fragments per sub-tile (half of the wave tile)
@@ -186,110 +193,6 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         for (int q = 0; q < DW; ++q) dma16(rw, dst + q * 1024, gw[hh][q], koff);
     };
 
-    // ---- NF4 weight modes: the W half-tiles do not come by DMA.  Each thread loads the packed codes of 16 weights of a
-    //      half-tile (+ their absmax) into registers one K-tile ahead (inline asm: the loads and their counted waits stay
-    //      outside the compiler's bookkeeping, like the DMAs of the attention kernels) and, in the phase where the bf16
-    //      kernel would issue the half-tile's DMA, dequantises them — code table value x absmax in fp32, rounded to bf16:
-    //      bit-identical to vft_nf4_dequant — into the same swizzled LDS image.  The 16-entry fp32 table is replicated
-    //      over the 32 banks (entry e of lane l at e * 128 + (l & 31) * 4: conflict-free) in the idle upper half of the
-    //      epilogue region, re-written after every epilogue.
-    //        mode 1: thread -> (weight row = tile row tid >> 2, 16 consecutive k): one 8-byte code load, two 16-byte writes
-    //        mode 2: thread -> (two consecutive reduction rows 2 (tid >> 4) (+1), 8 consecutive features 8 (tid & 15)):
-    //                one dword of codes per row; the pair (row, row + 1) of a feature is one 4-byte write; the features are
-    //                visited rotated by the feature group so that a wave's writes hit 16 banks at most twice.
-    constexpr int WQ = C::WQ;
-    constexpr int NQ = WQ == 1 ? 2 : 4;  // vector-memory operations per issue_q
-    const __amdgpu_buffer_rsrc_t rqc = __builtin_amdgcn_make_buffer_rsrc((void*)p.q_packed, 0, WQ ? (int)((int64_t)p.QN * p.QK / 2) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rqa = __builtin_amdgcn_make_buffer_rsrc((void*)p.q_absmax, 0, WQ ? (int)((int64_t)p.QN * p.QK / 16) : 0, 0x00020000);
-    unsigned char* const lut = sm8 + 2 * TILE + 16 * 1024;
-    // codes / absmax of the half-tiles (hh = 0, 1) in flight.  Every asm load writes a whole variable (never one element of a
-    // vector: the insert would be a register copy executed before the data has arrived): mode 1 uses c2 + a0, mode 2 c0, c1, a0, a1
-    struct QRegs {
-        u32x2 c2;
-        unsigned c0, c1;
-        float a0, a1;
-    };
-    QRegs qr[2];
-    // (the lane's code / absmax offsets are recomputed at every request from an opaque copy of the thread id: four registers held
-    // across the main loop would spill there)
-    int qn0 = 0;  // first output feature of the current tile (scalar)
-    auto setup_q = [&](int n0) { qn0 = n0; };
-    auto q_offsets = [&](int hh, int& vc, int& va, int& vc1, int& va1) {
-        int ot = tid;
-        asm volatile("" : "+v"(ot));
-        if constexpr (WQ == 1) {
-            const int n = min(qn0 + hh * (BN / 2) + (ot >> 2), p.N - 1);
-            vc = n * (p.QK / 2) + (ot & 3) * 8;
-            va = n * (p.QK / 64) * 4;
-            vc1 = va1 = 0;
-        } else {
-            const int npair = ot >> 4, kp0 = min(qn0 + hh * (BN / 2) + (ot & 15) * 8, p.N - 8);
-            vc = npair * p.QK + kp0 / 2;
-            va = (2 * npair * (p.QK / 64) + (kp0 >> 6)) * 4;
-            vc1 = vc + p.QK / 2;
-            va1 = va + (p.QK / 64) * 4;
-        }
-    };
-    auto load_q = [&](int t, int hh, QRegs& q) {
-        int vc, va, vc1, va1;
-        q_offsets(hh, vc, va, vc1, va1);
-        if constexpr (WQ == 1) {
-            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(q.c2) : "v"(vc), "s"(rqc), "s"(t * 32) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q.a0) : "v"(va), "s"(rqa), "s"(t * 4) : "memory");
-        } else if constexpr (WQ == 2) {
-            const int so = t * 32 * p.QK, sa = t * p.QK * 4;
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q.c0) : "v"(vc), "s"(rqc), "s"(so) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q.c1) : "v"(vc1), "s"(rqc), "s"(so) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q.a0) : "v"(va), "s"(rqa), "s"(sa) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q.a1) : "v"(va1), "s"(rqa), "s"(sa) : "memory");
-        }
-    };
-    // counted wait that also pins the registers the loads write (the compiler must not touch them before it)
-#define L8_QWAIT(q, N)                                                                                                          \
-    do {                                                                                                                        \
-        if constexpr (WQ == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"((q).c2), "+v"((q).a0) : "n"(N) : "memory");            \
-        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"((q).c0), "+v"((q).c1), "+v"((q).a0), "+v"((q).a1) : "n"(N) : "memory"); \
-    } while (0)
-    auto store_q = [&](int buf, int hh, const QRegs& q) {
-        unsigned char* hb = sm8 + buf * TILE + 2 * XH + hh * WH;
-        // lane-constant addresses recomputed from an opaque copy of the thread id: held across the main loop they would cost
-        // registers it does not have (the same device as the epilogue's `etid`)
-        int ot = tid;
-        asm volatile("" : "+v"(ot));
-        const unsigned char* lb = lut + ((ot & 31) << 2);
-        auto lut_at = [&](unsigned nib) { return *reinterpret_cast<const float*>(lb + (nib << 7)); };
-        if constexpr (WQ == 1) {
-            const int row = ot >> 2, q4 = ot & 3;
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                bf16x8 o;
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    o[2 * bb] = (bf16_t)(lut_at((q.c2[w] >> (8 * bb + 4)) & 15u) * q.a0);
-                    o[2 * bb + 1] = (bf16_t)(lut_at((q.c2[w] >> (8 * bb)) & 15u) * q.a0);
-                }
-                *reinterpret_cast<bf16x8*>(hb + row * 128 + (((2 * q4 + w) ^ (row & 7)) << 4)) = o;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if constexpr (WQ == 2) {
-            const int npair = ot >> 4, kg = ot & 15;
-            unsigned char* wb = hb + kg * 1024 + (npair & 3) * 4;
-            const int ch = npair >> 2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = (j + kg) & 7, sh = 4 * (e ^ 1);
-                bf16x2 o;
-                o[0] = (bf16_t)(lut_at((q.c0 >> sh) & 15u) * q.a0);
-                o[1] = (bf16_t)(lut_at((q.c1 >> sh) & 15u) * q.a1);
-                *reinterpret_cast<bf16x2*>(wb + e * 128 + ((ch ^ e) << 4)) = o;
-                if (j == 3) __builtin_amdgcn_sched_barrier(0);  // two batches of four: eight table values in flight, not sixteen
-            }
-        }
-    };
-    auto write_lut = [&]() {
-        if constexpr (WQ != 0) reinterpret_cast<float*>(lut)[tid] = p.q_code[tid >> 5];
-    };
-
     // ---- fragment read offsets (bytes inside a half-tile): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 kk + lq;
     //      row & 7 == lane & 7 (sub-tile bases are multiples of 16 rows)
     const int sw = ((lq ^ (lane & 7)) << 4);
@@ -327,88 +230,82 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
     const int nkt = p.K / 64;
-    // One K-tile = TWO phases of 32 MFMAs per wave: (X0, W0) + (X0, W1), then (X1, W1) + (X1, W0); has1 / has2 / has3: tiles
-    // t+1 / t+2 / t+3 exist (wave-uniform).  Round 2 ran four phases of 16: half as many hand-overs between the two wave groups
-    // (each costs the barrier's release plus the first operands' latency) is worth 4-7 % at K >= 3072, same registers, same DMA
-    // accounting.  Also tried and measured: fragment reads in the tail of the previous burst (6 % slower),
-    // four barriers per K-tile without the enforced alternation (2-5 % slower), a third of the reads left out (+2-5 % only:
-    // LDS bandwidth is not the bound).
-    // NF4 modes: W1 of tile t+1 is dequantised in phase A (into the other buffer: its W1 slot was last read one K-tile ago),
-    // W0 of tile t+2 in phase B (this buffer's W0 slot was read in phase A); each from codes requested one K-tile earlier.
-    auto tile = [&](int t, auto BUFc, bool has1, bool has2, bool has3) {
+    // One K-tile = four phases.  has1 / has2: tiles t+1 / t+2 exist (wave-uniform).
+    // (Tried in round 3, measured A/B on one MI355X and reverted: issuing each phase's fragment reads in the TAIL of the MFMA
+    // burst that frees their registers — X0 / W0 of the next tile behind phase 3, W1 behind phase 0, X1 behind phase 1 —
+    // instead of at the head of the consuming phase.  6 % SLOWER on the SDXL shapes (forward 85.5 -> 90.7 ms per step,
+    // data gradient 80.1 -> 84.0): the heads are already shorter than the 256-cycle bursts they run beside, so the reads
+    // were hidden where they were, and behind the burst they lengthen the computing group's own interval.)
+    auto tile = [&](int t, auto BUFc, bool has1, bool has2) {
         constexpr int BUF = decltype(BUFc)::value;
         const unsigned char* tb = sm8 + BUF * TILE;
-        // ---- phase A: (X0, W0), (X0, W1); re-fills X1 of the other buffer (tile t+1) ----
+#if L8_TWO_PHASE
+        // two phases of 32 MFMAs per wave: (X0, W0) + (X0, W1), then (X1, W1) + (X1, W0) — half as many hand-overs between the
+        // two wave groups per K-tile (each costs the barrier's release plus the first operands' latency)
         read_x(tb, 0);
         read_w(tb, 0, w0);
         read_w(tb, 1, w1);
         if (has1) stage_x(t + 1, BUF ^ 1, 1);
-        if constexpr (WQ != 0) {
-            if (has1) {
-                // behind W1(t+1)'s codes: X0(t+1), W0(t+2)'s codes, X1(t+1)   (tile 0: the top-of-tile wait covered them)
-                if (has3) L8_QWAIT(qr[1], NQ + 2 * DX);
-                else L8_QWAIT(qr[1], 0);
-                store_q(BUF ^ 1, 1, qr[1]);
-                if (has2) load_q(t + 2, 1, qr[1]);
-            }
-        }
-        lgk0();  // the X0 / W0 / W1 slots are re-filled in the next phase: their reads are done before this rendezvous
+        lgk0();  // X0 / W0 / W1 slots are re-filled in the next phase
         bar();
         mma(acc[0], 0, w0);
         mma(acc[0], 1, w1);
         bar();
-        // ---- phase B: (X1, W1), (X1, W0) from registers; re-fills X0, W0, W1 (tile t+2); everything of tile t+1 has landed
-        //      after the wait ----
         read_x(tb, 1);
-        if constexpr (WQ == 0) {
-            if (has2) {
-                stage_x(t + 2, BUF, 0);
-                stage_w(t + 2, BUF, 0);
-                stage_w(t + 2, BUF, 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+        if (has2) {
+            stage_x(t + 2, BUF, 0);
+            stage_w(t + 2, BUF, 0);
+            stage_w(t + 2, BUF, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
         } else {
-            if (has2) {
-                stage_x(t + 2, BUF, 0);
-                // behind W0(t+2)'s codes: X1(t+1), W1(t+2)'s codes, X0(t+2)
-                if (has3) L8_QWAIT(qr[0], NQ + 2 * DX);
-                else L8_QWAIT(qr[0], 0);
-                store_q(BUF, 0, qr[0]);
-                if (has3) load_q(t + 3, 0, qr[0]);
-            }
-            // X1 of tile t+1 has landed; behind it W1(t+2)'s codes, X0(t+2) and W0(t+3)'s codes stay in flight
-            if (has3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * NQ) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();
         lgk0();
         mma(acc[1], 1, w1);
         mma(acc[1], 0, w0);
         bar();
+        return;
+#endif
+        // ---- phase 0: quadrant (X0, W0); re-fills X1 of the other buffer (tile t+1) ----
+        read_x(tb, 0);
+        read_w(tb, 0, w0);
+        if (has1) stage_x(t + 1, BUF ^ 1, 1);
+        lgk0();  // X0's slot is re-filled in the next phase: its reads are done before this rendezvous
+        bar();
+        mma(acc[0], 0, w0);
+        if (!L8_ONE_BAR) bar();
+        // ---- phase 1: (X0, W1); re-fills X0 (tile t+2).  W1's slot is re-filled two phases later, so its reads may
+        //      complete behind the rendezvous ----
+        read_w(tb, 1, w1);
+        if (has2) stage_x(t + 2, BUF, 0);
+        bar();
+        lgk0();
+        mma(acc[0], 1, w1);
+        if (!L8_ONE_BAR) bar();
+        // ---- phase 2: (X1, W1); re-fills W0 ----
+#ifndef L8_EXP_SKIPREAD  // experiment (wrong results): a third of the fragment reads left out, to see what the LDS pipe costs
+        read_x(tb, 1);
+#endif
+        if (has2) stage_w(t + 2, BUF, 0);
+        bar();
+        lgk0();
+        mma(acc[1], 1, w1);
+        if (!L8_ONE_BAR) bar();
+        // ---- phase 3: (X1, W0 from registers); re-fills W1; everything of tile t+1 has landed after the wait (X0, W0,
+        //      W1 of tile t+2 stay in flight) ----
+        if (has2) {
+            stage_w(t + 2, BUF, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        bar();
+        mma(acc[1], 0, w0);
+        if (!L8_ONE_BAR) bar();
     };
     // first K-tile complete; X0 / W0 / W1 of the second in flight (its X1 follows in phase 0)
-    // NF4 modes: K-tiles 0 and 1 of the W operand dequantised right away (the table is intact: written before the first
-    // tile, re-written behind every epilogue); the X DMAs are issued behind the code loads and stay in flight
-    auto prologue_q = [&](int n0) {
-        setup_q(n0);
-        QRegs q1;
-        load_q(0, 0, qr[0]);
-        load_q(0, 1, qr[1]);
-        load_q(1, 0, q1);
-        stage_x(0, 0, 0);
-        stage_x(0, 0, 1);
-        stage_x(1, 1, 0);
-        L8_QWAIT(qr[0], 3 * DX);
-        L8_QWAIT(qr[1], 3 * DX);
-        L8_QWAIT(q1, 3 * DX);
-        store_q(0, 0, qr[0]);
-        store_q(0, 1, qr[1]);
-        store_q(1, 0, q1);
-    };
     auto prologue = [&]() {
-        if constexpr (WQ != 0) return;
         stage_x(0, 0, 0);
         stage_w(0, 0, 0);
         stage_w(0, 0, 1);
@@ -441,12 +338,6 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     decode(vt, m0, n0);
     setup(m0, n0);
     ext_dma(m0, n0);
-    if constexpr (WQ != 0) {
-        write_lut();
-        lgk0();
-        bar();
-        prologue_q(n0);
-    }
     prologue();
 #ifdef L8_STAMPS
     int stamp_it = 0;
@@ -455,20 +346,13 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         L8_STAMP(0);
         // the stores of the previous tile's epilogue are younger than these DMAs, so the count below (which assumes the
         // youngest operations are the second K-tile's DMAs) can only wait for MORE than it needs
-        if constexpr (WQ != 0) {
-            // W1(1)'s codes (dequantised in phase A of K-tile 0) and W0(2)'s (phase B) on their way; the wait leaves only the
-            // latter in flight: everything older — the X halves of K-tiles 0 / 1 included — has landed
-            load_q(1, 1, qr[1]);
-            load_q(2, 0, qr[0]);
-            L8_QWAIT(qr[1], NQ);
-            lgk0();
-        } else if (nkt > 1) {
+        if (nkt > 1) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();
-        if (grp == 1) bar();  // stagger the groups by one barrier
+        if (!L8_ONE_BAR && grp == 1) bar();  // stagger the groups by one barrier
         L8_STAMP(1);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -483,12 +367,12 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         {
             int t = 0;
             for (; t + 1 < nkt; t += 2) {
-                tile(t, std::integral_constant<int, 0>{}, true, t + 2 < nkt, t + 3 < nkt);
-                tile(t + 1, std::integral_constant<int, 1>{}, t + 2 < nkt, t + 3 < nkt, t + 4 < nkt);
+                tile(t, std::integral_constant<int, 0>{}, true, t + 2 < nkt);
+                tile(t + 1, std::integral_constant<int, 1>{}, t + 2 < nkt, t + 3 < nkt);
             }
-            if (t < nkt) tile(t, std::integral_constant<int, 0>{}, false, false, false);
+            if (t < nkt) tile(t, std::integral_constant<int, 0>{}, false, false);
         }
-        if (grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
+        if (!L8_ONE_BAR && grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
         L8_STAMP(2);
 
         // ---- the next tile's first DMAs fly while this tile is written out --------------------------------------
@@ -498,8 +382,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         if (more) {
             decode(vn, m0, n0);
             setup(m0, n0);
-            if constexpr (WQ != 0) prologue_q(n0);
-            prologue();
+                    prologue();
         }
 
         L8_STAMP(3);
@@ -618,7 +501,6 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
 #endif
         if (!more) break;
         ext_dma(m0, n0);  // behind the last pass's barrier: the region is idle again
-        write_lut();      // (NF4 modes; visible to every wave after the next tile's first barrier)
         vt = vn;
     }
 }
@@ -674,21 +556,6 @@ void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
         else if (cfg == 2) launch8<C8<256, 128, 4, false>>(p, st);
         else launch8<C8<128, 128, 2, false>>(p, st);
     }
-}
-
-bool vft_lin8_nf4_fits(const Lin8Params& p, int mode) {
-    const int64_t lim = (1LL << 31) - 4096;
-    const int64_t rows = p.x_rows > 0 ? p.x_rows : p.M;
-    return (mode == 1 || mode == 2) && p.K % 64 == 0 && p.K >= 256 && p.QK % 64 == 0 && p.QN % 64 == 0 && p.N % 8 == 0 && p.N >= 8 &&
-           ((rows - 1) * p.ldx + p.K) * 2 < lim && (int64_t)p.QN * p.QK / 2 < lim;
-}
-void vft_lin8_launch_nf4(Lin8Params p, int mode, hipStream_t st) {
-    static const int64_t nt_bytes = (int64_t)L8_NT_BYTES;
-    p.nt_store = (int64_t)(p.M - p.m_begin) * p.N * 2 > nt_bytes;
-    p.x_bytes = (int)x_extent(p, false);
-    p.w_bytes = 0;
-    if (mode == 1) launch8<C8<256, 256, 2, false, 1>>(p, st);
-    else launch8<C8<256, 256, 2, false, 2>>(p, st);
 }
 
 // Which tile.  Workgroups are persistent, so a launch costs ceil(tiles / resident slots) rounds of one tile each; a tile
