@@ -12,17 +12,15 @@
 //   * v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it than on 32x32x16 at equal cycles/flop),
 //     weight = A operand, so an accumulator register group is 4 consecutive output features of one token.
 //   * Each K-tile is staged as FOUR half-tiles (X0, W0, W1, X1: rows 0..BM/2, BM/2..BM of x, likewise W) by LDS-DMA
-//     (global_load_lds_dwordx4).  A wave's output tile takes WM/2 rows from EACH X half and WN/2 columns from each
-//     W half, so the four phases of a K-tile — the quadrants (X0,W0) (X0,W1) (X1,W1) (X1,W0) — free the half-tile
-//     slots one after the other and every phase re-fills exactly one slot:
-//         phase 0  reads X0, W0      issues X1 of tile t+1
-//         phase 1  reads W1          issues X0 of tile t+2      (X0's slot was last read one phase earlier)
-//         phase 2  reads X1          issues W0 of tile t+2
-//         phase 3  (W0 kept in regs) issues W1 of tile t+2,  s_waitcnt vmcnt(X0+W0+W1 of t+2 stay in flight)
+//     (buffer_load ... lds).  A wave's output tile takes WM/2 rows from EACH X half and WN/2 columns from each W half; a
+//     K-tile is two phases of two quadrants each (round 3; four one-quadrant phases in round 2):
+//         phase A  reads X0, W0, W1   quadrants (X0,W0) (X0,W1)   issues X1 of tile t+1
+//         phase B  reads X1           quadrants (X1,W1) (X1,W0)   issues X0, W0, W1 of tile t+2, s_waitcnt vmcnt(those three
+//                                                                 stay in flight)
 //     i.e. two K-tile buffers (2 x 64 KiB at 256x256) and three half-tiles always in flight across the barriers;
 //     vmcnt is never drained inside the loop.
 //   * The two 4-wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same program one barrier apart,
-//     so on every SIMD one wave issues its 16 MFMAs while its partner does its fragment reads and DMA issue.
+//     so on every SIMD one wave issues its 32 MFMAs while its partner does its fragment reads and DMA issue.
 //   * LDS image is lane-linear per DMA (8 rows x 128 B per wave-instruction); the bank swizzle
 //     chunk' = chunk ^ (row & 7) is applied to the per-lane SOURCE chunk and again on the ds_read_b128 fragment
 //     reads (conflict-free for the 16x16x32 operand: 16 rows x 4 k-chunks per instruction).
@@ -51,15 +49,6 @@ __device__ unsigned long long g_l8_stamps[512][8][12];
 // outputs above this size are stored with the non-temporal hint (see the epilogue)
 #ifndef L8_NT_BYTES
 #define L8_NT_BYTES (16ll << 20)
-#endif
-
-// experiment: L8_ONE_BAR=1 drops the barrier behind every MFMA burst and the one-barrier stagger of the two wave groups
-// (4 instead of 8 barriers per K-tile: what slot re-use needs; the groups then interleave as the hardware arbitrates)
-#ifndef L8_ONE_BAR
-#define L8_ONE_BAR 0
-#endif
-#ifndef L8_TWO_PHASE
-#define L8_TWO_PHASE 1
 #endif
 
 namespace {
@@ -230,27 +219,27 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
     const int nkt = p.K / 64;
-    // One K-tile = four phases.  has1 / has2: tiles t+1 / t+2 exist (wave-uniform).
-    // (Tried in round 3, measured A/B on one MI355X and reverted: issuing each phase's fragment reads in the TAIL of the MFMA
-    // burst that frees their registers — X0 / W0 of the next tile behind phase 3, W1 behind phase 0, X1 behind phase 1 —
-    // instead of at the head of the consuming phase.  6 % SLOWER on the SDXL shapes (forward 85.5 -> 90.7 ms per step,
-    // data gradient 80.1 -> 84.0): the heads are already shorter than the 256-cycle bursts they run beside, so the reads
-    // were hidden where they were, and behind the burst they lengthen the computing group's own interval.)
+    // One K-tile = TWO phases of 32 MFMAs per wave: (X0, W0) + (X0, W1), then (X1, W1) + (X1, W0 from registers); has1 / has2:
+    // tiles t+1 / t+2 exist (wave-uniform).  Round 2 ran four phases of 16: half as many hand-overs between the two wave groups
+    // (each costs the barrier's release plus the first operands' latency) is worth 4-7 % at K >= 3072, with the same registers
+    // and the same DMA accounting.  Also tried and measured: fragment reads in the tail of the previous burst
+    // (6 % slower), four barriers per K-tile without the enforced alternation of the groups (2-5 % slower), a third of the
+    // fragment reads left out (+2-5 % only: LDS bandwidth is not the bound).
     auto tile = [&](int t, auto BUFc, bool has1, bool has2) {
         constexpr int BUF = decltype(BUFc)::value;
         const unsigned char* tb = sm8 + BUF * TILE;
-#if L8_TWO_PHASE
-        // two phases of 32 MFMAs per wave: (X0, W0) + (X0, W1), then (X1, W1) + (X1, W0) — half as many hand-overs between the
-        // two wave groups per K-tile (each costs the barrier's release plus the first operands' latency)
+        // ---- phase A: (X0, W0), (X0, W1); re-fills X1 of the other buffer (tile t+1) ----
         read_x(tb, 0);
         read_w(tb, 0, w0);
         read_w(tb, 1, w1);
         if (has1) stage_x(t + 1, BUF ^ 1, 1);
-        lgk0();  // X0 / W0 / W1 slots are re-filled in the next phase
+        lgk0();  // the X0 / W0 / W1 slots are re-filled in the next phase: their reads are done before this rendezvous
         bar();
         mma(acc[0], 0, w0);
         mma(acc[0], 1, w1);
         bar();
+        // ---- phase B: (X1, W1), (X1, W0); re-fills X0, W0, W1 (tile t+2); everything of tile t+1 has landed after the wait
+        //      (the three half-tiles of tile t+2 stay in flight) ----
         read_x(tb, 1);
         if (has2) {
             stage_x(t + 2, BUF, 0);
@@ -265,44 +254,6 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         mma(acc[1], 1, w1);
         mma(acc[1], 0, w0);
         bar();
-        return;
-#endif
-        // ---- phase 0: quadrant (X0, W0); re-fills X1 of the other buffer (tile t+1) ----
-        read_x(tb, 0);
-        read_w(tb, 0, w0);
-        if (has1) stage_x(t + 1, BUF ^ 1, 1);
-        lgk0();  // X0's slot is re-filled in the next phase: its reads are done before this rendezvous
-        bar();
-        mma(acc[0], 0, w0);
-        if (!L8_ONE_BAR) bar();
-        // ---- phase 1: (X0, W1); re-fills X0 (tile t+2).  W1's slot is re-filled two phases later, so its reads may
-        //      complete behind the rendezvous ----
-        read_w(tb, 1, w1);
-        if (has2) stage_x(t + 2, BUF, 0);
-        bar();
-        lgk0();
-        mma(acc[0], 1, w1);
-        if (!L8_ONE_BAR) bar();
-        // ---- phase 2: (X1, W1); re-fills W0 ----
-#ifndef L8_EXP_SKIPREAD  // experiment (wrong results): a third of the fragment reads left out, to see what the LDS pipe costs
-        read_x(tb, 1);
-#endif
-        if (has2) stage_w(t + 2, BUF, 0);
-        bar();
-        lgk0();
-        mma(acc[1], 1, w1);
-        if (!L8_ONE_BAR) bar();
-        // ---- phase 3: (X1, W0 from registers); re-fills W1; everything of tile t+1 has landed after the wait (X0, W0,
-        //      W1 of tile t+2 stay in flight) ----
-        if (has2) {
-            stage_w(t + 2, BUF, 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        bar();
-        mma(acc[1], 0, w0);
-        if (!L8_ONE_BAR) bar();
     };
     // first K-tile complete; X0 / W0 / W1 of the second in flight (its X1 follows in phase 0)
     auto prologue = [&]() {
@@ -352,7 +303,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();
-        if (!L8_ONE_BAR && grp == 1) bar();  // stagger the groups by one barrier
+        if (grp == 1) bar();  // stagger the groups by one barrier
         L8_STAMP(1);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -372,7 +323,7 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
             }
             if (t < nkt) tile(t, std::integral_constant<int, 0>{}, false, false);
         }
-        if (!L8_ONE_BAR && grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
+        if (grp == 0) bar();  // both groups are past their last fragment reads: the K-tile buffers are free
         L8_STAMP(2);
 
         // ---- the next tile's first DMAs fly while this tile is written out --------------------------------------

@@ -233,35 +233,31 @@ __global__ __launch_bounds__(NT, 2) void wg8_kernel(Wg8Params p) {
     auto lgk0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
     // One reduction tile = four phases (the schedule of lin8: see linear8.hip)
+    // two phases of 32 MFMAs per wave and reduction tile (lin8's round-3 schedule: half as many hand-overs between the groups)
     auto tile = [&](int t, auto BUFc, bool has1, bool has2) {
         constexpr int BUF = decltype(BUFc)::value;
         const unsigned char* tb = smw + BUF * TILE;
         read_x(tb, 0);
         read_w(tb, 0, w0);
+        read_w(tb, 1, w1);
         if (has1) stage_a(t + 1, BUF ^ 1, 1);
         lgk0();
         bar();
         mma(acc[0], 0, w0);
-        bar();
-        read_w(tb, 1, w1);
-        if (has2) stage_a(t + 2, BUF, 0);
-        bar();
-        lgk0();
         mma(acc[0], 1, w1);
         bar();
         read_x(tb, 1);
-        if (has2) stage_b(t + 2, BUF, 0);
-        bar();
-        lgk0();
-        mma(acc[1], 1, w1);
-        bar();
         if (has2) {
+            stage_a(t + 2, BUF, 0);
+            stage_b(t + 2, BUF, 0);
             stage_b(t + 2, BUF, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DX + 2 * DW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();
+        lgk0();
+        mma(acc[1], 1, w1);
         mma(acc[1], 0, w0);
         bar();
     };
