@@ -249,8 +249,8 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        lgk0();  // X1's slot is re-filled by the first phase of the next tile: its reads are done before this rendezvous
         bar();
-        lgk0();
         mma(acc[1], 1, w1);
         mma(acc[1], 0, w0);
         bar();
