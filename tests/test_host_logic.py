@@ -237,6 +237,29 @@ def test_weight_gradient_scratch_sizes_and_argument_checks():
     assert lib.vft_norm_bwd_params(one, one, z, z, z, one, one, one, 1024, 640, 640, 1024, 0, 0, 0, z) == 1  # layer norm without mean
 
 
+def test_attention_backward_workspace_follows_the_form_that_will_run():
+    """vft_attn_bwd picks its form from the scratch it gets (include/vft_hip.h): the size function must account for the
+    running-dQ plane(s) of the one-pass form (head_dim 64, more than 128 keys), for dS^T of the stored-dS form (head_dim
+    128 / 256, >= 512 queries and keys, Sq % 8 == 0) and for nothing but delta (+ split partials) otherwise.  Host only."""
+    from vision_ft_amd import _C
+
+    ws = _C.lib().vft_attn_bwd_workspace
+    rows = lambda B, H, S: (B * H * S + 3) // 4 * 4  # noqa: E731
+    # AuraFlow shape: delta + dS^T (bf16, rows padded to whole 32-query tiles) [+ 4 floats: the dQ GEMM writes its result directly]
+    B, H, S, D = 6, 12, 4360, 256
+    ds_floats = B * H * S * ((S + 31) // 32 * 32) // 2
+    assert ws(B, H, H, S, S, D) == rows(B, H, S) + ds_floats + 4
+    assert ws(B, H, H, S + 4, S, D) < ds_floats          # Sq % 8 != 0: the dq + dkdv pair
+    assert ws(B, H, H, 256, 256, D) < rows(B, H, 256) * 4 + 2 * 8 * B * H * 256 * D + 1  # short sequences: delta (+ split partials)
+    # one-pass form: -delta, -lse/scale and at least one fp32 plane of B*Hq*ceil(Sq/64)*64*D
+    B, H, S, D = 24, 10, 4096, 64
+    plane = B * H * ((S + 63) // 64) * 64 * D
+    n = ws(B, H, H, S, S, D)
+    assert n >= 2 * rows(B, H, S) + plane and (n - 2 * rows(B, H, S)) % plane == 0 and (n - 2 * rows(B, H, S)) // plane <= 4
+    assert ws(B, H, H, S, 77, D) < plane                 # the 77-key cross-attention stays on the pair
+    assert ws(0, H, H, S, S, D) == 0
+
+
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     import ctypes
 
