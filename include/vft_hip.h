@@ -329,6 +329,11 @@ int vft_nf4_dequant(void* out, const void* packed, const void* absmax, int absma
                     const float* nested_absmax, const float* nested_code, const float* code,
                     float nested_offset, int out_features, int in_features, void* stream);
 
+/* dst[C][R] = src[R][C]^T, bf16 (R, C and the row strides multiples of 8).  The per-step transposed copy of a trainable
+ * projection weight: autograd's data gradient dx = dy . W (torch.mm in the reference, src/models/sdxl/denoiser.py:62-64 under
+ * full fine-tune) runs as vft_linear_fwd on it. */
+int vft_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src, int64_t ld_dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -299,3 +299,17 @@ def test_plain_linear_on_the_fused_gemm(gpu):
     y.backward(dy)
     assert rel_err(w.grad.float(), hw.float() + wf.grad) < 1e-2
     assert rel_err(b.grad.float(), hb.float() + bf.grad) < 1e-2
+
+
+@pytest.mark.parametrize("R,C", [(1280, 640), (640, 5120), (72, 200), (8, 8)])
+def test_transpose_bf16_matches_torch(gpu, R, C):
+    """vft_transpose_bf16 (the per-step transposed copy of a trainable projection weight): bit-equal to .t().contiguous()."""
+    from vision_ft_amd import _C, kernels
+
+    w = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).to(torch.bfloat16).to(gpu)
+    out = torch.empty(C, R, dtype=torch.bfloat16, device=gpu)
+    _C.check(_C.lib().vft_transpose_bf16(w.data_ptr(), out.data_ptr(), R, C, C, R, kernels._stream()), "vft_transpose_bf16")
+    assert torch.equal(out, w.t().contiguous())
+    wp = torch.nn.Parameter(w)  # the trainable-weight path of the data gradient takes the kernel
+    assert torch.equal(kernels._transposed_weight(wp), w.t().contiguous())
+    assert _C.lib().vft_transpose_bf16(w.data_ptr(), out.data_ptr(), R + 1, C, C, R, kernels._stream()) == 1  # R % 8

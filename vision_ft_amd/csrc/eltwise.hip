@@ -368,3 +368,49 @@ extern "C" int vft_geglu_lora_bwd(const void* proj, const void* t, const void* l
     VFT_CHECK_LAUNCH("vft_geglu_lora_bwd");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// dst[C][R] = src[R][C]^T (bf16): the per-step transposed copy of a TRAINABLE projection weight, on which the data gradient
+// dx = dy . W runs as the same NT GEMM (kernels._transposed_weight; the frozen weights' copies are made once).  64 x 64 tiles
+// through LDS (rows padded by one dword: the column reads hit 32 different banks), 16-byte global accesses on both sides.
+// Replaces `weight.t().contiguous()`: ATen's generic strided copy ran the 323 weights of the SDXL full fine-tune at
+// 0.3 TB/s — 13 ms per step.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
+                                                        int64_t lds_, int64_t ldd) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 256 * q, row = idx >> 3, ch = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + row < R && c0 + ch * 8 < C) v = *reinterpret_cast<const u32x4*>(src + (int64_t)(r0 + row) * lds_ + c0 + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[row][ch * 8 + 2 * e] = (unsigned short)(v[e] & 0xffffu);
+            tile[row][ch * 8 + 2 * e + 1] = (unsigned short)(v[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 256 * q, col = idx >> 3, ch = idx & 7;  // output row = source column
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (unsigned)tile[ch * 8 + 2 * e][col] | ((unsigned)tile[ch * 8 + 2 * e + 1][col] << 16);
+        if (c0 + col < C && r0 + ch * 8 < R) *reinterpret_cast<u32x4*>(dst + (int64_t)(c0 + col) * ldd + r0 + ch * 8) = v;
+    }
+}
+}  // namespace
+
+extern "C" int vft_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src, int64_t ld_dst, void* stream) {
+    VFT_CHECK_ARG(src && dst, "vft_transpose_bf16: null pointer");
+    VFT_CHECK_ARG(R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ld_src >= C && ld_dst >= R,
+                  "vft_transpose_bf16: R, C and both row strides must be positive multiples of 8 (R=%d C=%d)", R, C);
+    VFT_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "vft_transpose_bf16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, R, C, ld_src, ld_dst);
+    VFT_CHECK_LAUNCH("vft_transpose_bf16");
+    return 0;
+}

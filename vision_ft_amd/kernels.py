@@ -914,7 +914,15 @@ def _transposed_weight(weight: torch.Tensor) -> torch.Tensor:
     """W^T (in, out) contiguous: the data gradient dy . W is the same NT GEMM on it.  Frozen weights keep the copy
     on the parameter object (288 GB of HBM: memory is not the constraint); trainable ones are transposed per call."""
     def make():
-        return weight.detach().t().contiguous()
+        w = weight.detach()
+        R, C = w.shape
+        if w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous() and R % 8 == 0 and C % 8 == 0:
+            out = torch.empty((C, R), dtype=torch.bfloat16, device=w.device)
+            with torch.cuda.device(w.device):
+                st = _C.lib().vft_transpose_bf16(_ptr(w), _ptr(out), R, C, C, R, _stream())
+            _C.check(st, "vft_transpose_bf16")
+            return out
+        return w.t().contiguous()
 
     if weight.requires_grad:
         return make()
