@@ -201,8 +201,9 @@ def per_call_roofline(prof: dict) -> dict:
 # hand-written kernels by family: (profile-key prefixes, HIP kernel name, roofline that bounds it)
 FAMILIES = {
     "linear_gemm": (("linear_fwd",), "lin8_kernel (vft_linear_fwd: base GEMM + bias + LoRA rank extension + skip, forward and data gradient)", "mfma"),
-    "attention_bwd": (("attn_bwd",), "attn_bwd1_kernel (one pass: head_dim 64 self-attention) / attn_bwd_dq3_kernel + attn_bwd_dkdv3_kernel (head_dim >= 128, "
-                                     "short key sequences) / attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (head_dim 96)", "mfma"),
+    "attention_bwd": (("attn_bwd",), "attn_bwd1_kernel (one pass: head_dim 64 self-attention) / attn_bwd_dkdv3_kernel<.., true> + batched wg8_kernel (stored dS: "
+                                     "head_dim >= 128) / attn_bwd_dq3_kernel + attn_bwd_dkdv3_kernel (short key sequences) / attn_bwd_dq_kernel + "
+                                     "attn_bwd_dkdv4_kernel (head_dim 96)", "mfma"),
     "attention_fwd": (("attn_fwd",), "attn_fwd_kernel (head_dim 64 / 96) / attn_fwd2_kernel (head_dim >= 128)", "mfma"),
     "conv3x3": (("conv3x3_fwd", "conv3x3_dgrad"), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
     "weight_grad": (("linear_wgrad", "conv3x3_wgrad"), "wg8_kernel (vft_linear_wgrad / vft_conv3x3_wgrad: weight gradients of trainable projections and 3x3 convolutions)", "mfma"),
