@@ -56,6 +56,32 @@ def test_attention_backward_properties_at_full_size(gpu):
     assert rel_err(dv.float().sum(2), torch.full((B, H, D), float(S), device=gpu)) < 5e-3
 
 
+def test_attention_backward_forms_agree_at_auraflow_size(gpu):
+    """AuraFlow's attention at full size (4 096 patches + 264 text tokens, 12 heads x 256): the stored-dS backward (the dK/dV
+    kernel writes dS^T, dQ is a batched GEMM on the weight-gradient kernel) against the dq + dkdv kernel pair on the same
+    inputs (vft_attn_variant 3), linearity in dO, and the row-sum identity of dV."""
+    from vision_ft_amd import kernels
+
+    B, H, S, D = 2, 12, 4360, 256
+    q, k, v = (_bf(gpu, B, S, H, D, seed=s).permute(0, 2, 1, 3).requires_grad_(True) for s in (21, 22, 23))  # (B, S, H, D) memory
+    g1, g2 = (_bf(gpu, B, S, H, D, seed=s).permute(0, 2, 1, 3) for s in (24, 25))
+    o = kernels.flash_attention(q, k, v)
+    ga = torch.autograd.grad(o, (q, k, v), g1, retain_graph=True)
+    gb = torch.autograd.grad(o, (q, k, v), g2, retain_graph=True)
+    gab = torch.autograd.grad(o, (q, k, v), (g1.float() + g2.float()).to(torch.bfloat16), retain_graph=True)
+    for x, y, z in zip(ga, gb, gab):
+        assert rel_err(z, x.float() + y.float()) < 1.5e-2
+    assert kernels._C.lib().vft_attn_variant(3) == 0
+    try:
+        gp = torch.autograd.grad(o, (q, k, v), g1, retain_graph=True)
+    finally:
+        kernels._C.lib().vft_attn_variant(0)
+    for x, y in zip(ga, gp):
+        assert rel_err(x, y.float()) < 6e-3
+    (dv,) = torch.autograd.grad(o, (v,), torch.ones_like(o))
+    assert rel_err(dv.float().sum(2), torch.full((B, H, D), float(S), device=gpu)) < 5e-3
+
+
 def test_conv3x3_properties_at_full_size(gpu):
     from vision_ft_amd import kernels
 
