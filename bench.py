@@ -216,6 +216,43 @@ FAMILIES = {
 }
 
 
+# short names for the ONE printed line (the long descriptions above go to the detail file)
+SHORT_KERNEL = {
+    "linear_gemm": "lin8_kernel (vft_linear_fwd)", "attention_bwd": "attn_bwd* kernels (vft_attn_bwd)", "attention_fwd": "attn_fwd* kernels (vft_attn_fwd)",
+    "conv3x3": "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd)", "weight_grad": "wg8_kernel (vft_linear_wgrad / vft_conv3x3_wgrad)",
+    "gemm_nf4": "NF4 projection GEMM (vft_linear_nf4)", "library_gemm": "hipBLASLt Cijk_* (not ours)", "lora_rank": "lora_down32 / lora_wgrad kernels",
+    "norms_activations": "norm / GroupNorm / GEGLU / SwiGLU kernels",
+}
+
+
+def compact_roofline(r: dict) -> dict:
+    """The roofline object of the printed line: the dominant family's figures + one [ms/step, fraction of its roofline] pair per
+    family.  Everything else (per-call table, kernel descriptions) is in the detail file."""
+    if not r:
+        return {}
+    keep = ("bound", "family", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step", "share_of_step", "step_mfma_frac")
+    out = {k: r.get(k) for k in keep}
+    out["kernel"] = SHORT_KERNEL.get(r.get("family"), r.get("kernel"))
+    note = r.get("traffic_note")
+    out["traffic_note"] = None if not note else note[:160]
+    out["families_ms_frac"] = {k: [v["ms_per_step"], v["frac"]] for k, v in r.get("families", {}).items()}
+    out["hand_written_ms_per_step"] = r.get("hand_written_ms_per_step")
+    out["library_and_aten_ms_per_step"] = r.get("library_and_aten_ms_per_step")
+    out["measured"] = r.get("measured")
+    return out
+
+
+def compact_config(c: dict) -> dict:
+    keep = ("workload", "resolution", "per_gpu_batch", "global_batch", "parallelism", "optimizer", "hip_graph", "trainable_params", "loss",
+            "peak_mem_gib", "algorithmic_tflop_per_image", "use_rope", "lora_key_set", "caption_lengths")
+    out = {k: c[k] for k in keep if k in c}
+    if "base_weights" in c:
+        out["base_weights"] = "NF4 in HBM, dequantised in the GEMM kernel" if "only copy" in c["base_weights"] else "NF4 state, bf16 compute cache (labelled option)"
+    if "buckets" in c:
+        out["buckets"] = {"grad_accum": c["buckets"]["grad_accum"], "n_buckets": len(c["buckets"]["buckets_wh"])}
+    return out
+
+
 def family_table(prof: dict, steps: int) -> dict:
     out = {}
     for fam, (prefixes, kname, bound) in FAMILIES.items():
@@ -405,6 +442,9 @@ def main():
             loss = step()
         fence()
         elapsed = time.perf_counter() - t0
+        # read the last step's loss NOW: under graph replay it is a static tensor inside the graph's private pool, which is
+        # released below (round 3 printed whatever the eager pass had written there since: negative / nan "losses")
+        last_loss = float(loss.detach().float())
         prof_steps = steps
         peak_timed = torch.cuda.max_memory_allocated(device) / 2**30
         eager_ms = None
@@ -475,7 +515,7 @@ def main():
                 "config": {"workload": workload, "resolution": "mixed buckets ~1 MP" if bucket_note else "1024x1024", "per_gpu_batch": batch,
                            "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": "AdamW(fused)", "hip_graph": use_graph,
                            "gemm_table": bool(gemm_table), "lora_in_gemm": bool(kernels.FUSED_LORA_GEMM),
-                           "trainable_params": sum(p.numel() for p in params), "loss": round(float(loss.detach()), 5),
+                           "trainable_params": sum(p.numel() for p in params), "loss": round(last_loss, 5),
                            "peak_mem_gib": round(peak_timed, 1), "algorithmic_tflop_per_image": F_ALG[workload],
                            **({"buckets": bucket_note} if bucket_note else {}),
                            **({"base_weights": "NF4 (blocksize 64, double-quantised absmax): " + (
@@ -518,17 +558,41 @@ def main():
             legs["aura_lora_yaml124"] = run_workload("aura_lora", default_batch["aura_lora"], 3, 2, aura_keys="yaml124")
 
     if rank == 0:
-        out = {
+        base = {
             "metric": "train images/sec at 1024^2", "value": main_res["value"], "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": main_res["config"], "roofline": main_res["roofline"],
         }
+        detail = {**base, "config": main_res["config"], "roofline": main_res["roofline"]}
         if legs:
-            out["workloads"] = {k: {"metric": "train images/sec at 1024^2", "unit": "images/s", **v} for k, v in legs.items()}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(threads=physical_cores())
-        print(json.dumps(out))
+            detail["workloads"] = {k: {"metric": "train images/sec at 1024^2", "unit": "images/s", **v} for k, v in legs.items()}
+        cpu = cpu_baseline(threads=physical_cores()) if world == 1 and not args.no_cpu_baseline else None
+        if cpu:
+            detail["cpu_baseline"] = cpu
+        # the full record (per-call table, every leg's family table and config) goes to a file and to stderr; stdout carries ONE
+        # compact JSON line (round 3's 34 KB line was longer than the driver's capture and could not be parsed)
+        detail_path = None
+        for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+            try:
+                os.makedirs(d, exist_ok=True)
+                detail_path = os.path.join(d, f"bench_detail_n{world}.json")
+                with open(detail_path, "w") as f:
+                    json.dump(detail, f, indent=1)
+                break
+            except OSError:
+                detail_path = None
+        print("bench detail: " + json.dumps(detail), file=sys.stderr, flush=True)
+        out = {**base, "config": compact_config(main_res["config"]), "roofline": compact_roofline(main_res["roofline"])}
+        if legs:
+            out["workloads"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "per_gpu_batch": v["config"]["per_gpu_batch"],
+                                    "step_mfma_frac": v["roofline"].get("step_mfma_frac"), "dominant": v["roofline"].get("family"),
+                                    "dominant_frac": v["roofline"].get("frac"), "dominant_share": v["roofline"].get("share_of_step")}
+                                for k, v in legs.items()}
+        if cpu:
+            out["cpu_baseline"] = cpu
+        out["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path else "stderr"
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
