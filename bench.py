@@ -434,12 +434,16 @@ def main():
             step = eager_step
 
         for _ in range(warmup):
-            step()
+            wl = step()
+            if os.environ.get("VFT_BENCH_DEBUG_LOSS"):  # diagnostic only (synchronises every step)
+                print(f"[debug] {workload} warm-up loss {float(wl.detach().float()):.6f}", file=sys.stderr, flush=True)
         kernels.set_profiling(rank == 0 and not use_graph)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
+            if os.environ.get("VFT_BENCH_DEBUG_LOSS"):  # diagnostic only (synchronises every step)
+                print(f"[debug] {workload} loss {float(loss.detach().float()):.6f}", file=sys.stderr, flush=True)
         fence()
         elapsed = time.perf_counter() - t0
         # read the last step's loss NOW: under graph replay it is a static tensor inside the graph's private pool, which is

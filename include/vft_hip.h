@@ -266,13 +266,24 @@ int vft_gate_residual(const void* residual, const void* gate, const void* y, voi
  * transpose_w = 1: y[M,in]  = x[M,out] . W   (+ ext ...)   -- the data gradient
  * W = bitsandbytes NF4 payload [out*in/2] bytes (bnb.py:37-129 layout, blocksize 64), absmax = one fp32 per
  * 64 weights (a double-quantised checkpoint's absmax is expanded once at load time), code = the 16-entry map.
- * Dequantisation happens in the staging threads of the GEMM; only 4-bit codes + absmax travel from HBM.
+ * Only 4-bit codes + absmax persist in HBM.  Two forms of the dequantisation, both inside the GEMM launch:
+ *   workspace != NULL (round 4, what the product passes): the launch dequantises the weight ONCE — every workgroup of the
+ *     persistent grid converts its share of the codes into the workspace (bf16 image of W, or of W^T for the data
+ *     gradient), the grid meets at a barrier, and the bf16 main loop of the second-generation kernel runs on the image
+ *     (which stays in the 256 MB Infinity Cache: <= 28 MB for Lumina2's largest layer).  Bit-identical to vft_linear_fwd on
+ *     vft_nf4_dequant's output.  The workspace (vft_linear_nf4_workspace bytes, 256-byte aligned) belongs to the caller, may
+ *     be shared by every NF4 layer of a stream, and its FIRST 16 KiB (barrier words) must be zero before the first
+ *     launch; every launch leaves them zero (graph replay needs no memset).  Word 2 is an error flag: a launch that could
+ *     not assemble its grid at the barrier within a bounded wait sets it instead of hanging.
+ *   workspace == NULL, or a shape the second-generation kernel does not take (K % 64 != 0, r = 32, operands >= 2 GiB):
+ *     dequantisation in the staging threads of the first-generation kernel's K-loop (round 1-3).
  * in_features % 64 == 0 (and out_features % 64 == 0 for transpose_w); r in {4, 8, 16, 32}.
  */
+int64_t vft_linear_nf4_workspace(int out_features, int in_features);
 int vft_linear_nf4(const void* x, void* y, const void* bias, const void* residual, const void* ext_x,
                    const void* ext_w, const void* packed, const float* absmax, const float* code,
                    int out_features, int in_features, int M, int r, int64_t ldx, int64_t ldy,
-                   int64_t ldres, int transpose_w, void* stream);
+                   int64_t ldres, int transpose_w, void* workspace, int64_t ws_bytes, void* stream);
 
 /* ---- 3x3 convolution (stride 1, padding 1), channels-last, implicit GEMM ------------------------------
  * y[B,H,W,Cout] = conv3x3(x[B,H,W,Cin], w[Cout,3,3,Cin]) + bias.  w is the storage of a channels-last
@@ -333,6 +344,16 @@ int vft_nf4_dequant(void* out, const void* packed, const void* absmax, int absma
  * projection weight: autograd's data gradient dx = dy . W (torch.mm in the reference, src/models/sdxl/denoiser.py:62-64 under
  * full fine-tune) runs as vft_linear_fwd on it. */
 int vft_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src, int64_t ld_dst, void* stream);
+
+/* ---- mean of squares (the reduction of the MSE losses) --------------------------------------------------------
+ * out[0] = sum(x[i]^2) / n over a dense fp32 buffer: with x = prediction - target this is
+ * F.mse_loss(prediction, target, reduction="mean") of the reference's losses (src/modules/loss/diffusion.py:62-68,
+ * src/modules/loss/flow_match.py:85-96).  Two launches (fixed chunks -> 1024 partials in `scratch` -> ordered fold), no
+ * atomics, no memset node: bit-reproducible and safe to replay from a HIP graph (ATen's one-launch reduction meets through a
+ * semaphore buffer zeroed by a memset node; captured in the SDXL step it returned garbage after an idle-stream synchronize).
+ * scratch: vft_mean_sq_scratch_floats() floats.  x 16-byte aligned. */
+int64_t vft_mean_sq_scratch_floats(void);
+int vft_mean_sq(const float* x, float* out, float* scratch, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

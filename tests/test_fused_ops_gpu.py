@@ -313,3 +313,40 @@ def test_transpose_bf16_matches_torch(gpu, R, C):
     wp = torch.nn.Parameter(w)  # the trainable-weight path of the data gradient takes the kernel
     assert torch.equal(kernels._transposed_weight(wp), w.t().contiguous())
     assert _C.lib().vft_transpose_bf16(w.data_ptr(), out.data_ptr(), R + 1, C, C, R, kernels._stream()) == 1  # R % 8
+
+
+@pytest.mark.parametrize("shape,cl", [((24, 4, 128, 128), True), ((3, 16, 40, 24), False), ((1, 5), False), ((7, 4, 33, 17), True)])
+def test_mse_loss_reduction_kernel(gpu, shape, cl):
+    """kernels.mse_loss = F.mse_loss(pred.float(), target.float(), 'mean') (reference: src/modules/loss/diffusion.py:62-68): value
+    and gradient against fp64 math; a channels-last prediction against a contiguous target; bit-identical repeats; and replay
+    from a HIP graph around an idle-stream synchronize (where ATen's semaphore reduction went wrong in the captured step)."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(*shape, generator=g).to(torch.bfloat16).to(gpu)
+    if cl and pred.dim() == 4:
+        pred = pred.contiguous(memory_format=torch.channels_last)
+    target = torch.randn(*shape, generator=g).to(gpu)
+    pr = pred.detach().clone().requires_grad_(True)
+    loss = kernels.mse_loss(pr, target)
+    loss.backward()
+    want = ((pred.double() - target.double()) ** 2).mean()
+    assert loss.dtype == torch.float32 and loss.dim() == 0
+    assert abs(float(loss) - float(want)) < 2e-6 * float(want)
+    gw = (2.0 * (pred.double() - target.double()) / pred.numel())
+    assert rel_err(pr.grad.float().cpu(), gw.float().cpu()) < 4e-3  # the gradient is rounded to the prediction's bf16
+    assert torch.equal(kernels.mse_loss(pred, target), kernels.mse_loss(pred, target))
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        kernels.mse_loss(pred, target)
+    torch.cuda.current_stream().wait_stream(s_)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = kernels.mse_loss(pred, target)
+    for i in range(4):
+        if i == 2:
+            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()
+        graph.replay()
+        assert float(out) == float(loss)

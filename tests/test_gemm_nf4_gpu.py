@@ -94,9 +94,22 @@ def test_nf4_dequant_kernel_matches_oracle(gpu, double_quant):
     assert rel_err(got, wd) < 4e-3
 
 
+@pytest.fixture(params=["dequant_once", "dequant_in_loop"])
+def nf4_gemm_form(request):
+    """Both forms of vft_linear_nf4: the weight dequantised once per launch into the workspace (round 4, default) and
+    inside the K-loop by every row tile (round 3; what a call without a workspace runs)."""
+    from vision_ft_amd import kernels
+
+    old = kernels.NF4_DEQUANT_ONCE
+    kernels.NF4_DEQUANT_ONCE = request.param == "dequant_once"
+    yield request.param
+    kernels.NF4_DEQUANT_ONCE = old
+    assert not kernels.nf4_barrier_timed_out()
+
+
 @pytest.mark.parametrize("M,out_f,in_f,dq", [(520, 3840, 2304, True), (333, 2304, 9216, True), (77, 256, 128, False),
-                                             (1024, 9216, 2304, False)])
-def test_nf4_linear_forward_backward(gpu, M, out_f, in_f, dq):
+                                             (1024, 9216, 2304, False), (300, 192, 320, True)])
+def test_nf4_linear_forward_backward(gpu, nf4_gemm_form, M, out_f, in_f, dq):
     layer, wd, b, _ = _make_layer(gpu, out_f, in_f, dq)
     g = torch.Generator().manual_seed(4)
     x, gy = _bf(g, 2, M // 2 if M % 2 == 0 else M, in_f), None
@@ -113,7 +126,7 @@ def test_nf4_linear_forward_backward(gpu, M, out_f, in_f, dq):
 
 @pytest.mark.parametrize("M,out_f,in_f,r,dq,res", [(520, 3840, 2304, 4, True, False), (333, 2304, 2304, 8, True, True),
                                                    (1000, 256, 128, 16, False, True)])
-def test_qlora_linear_one_launch_per_direction(gpu, M, out_f, in_f, r, dq, res):
+def test_qlora_linear_one_launch_per_direction(gpu, nf4_gemm_form, M, out_f, in_f, r, dq, res):
     """NF4 base + LoRA (+ residual) through vft_lora_down + vft_linear_nf4 with the rank extension: output, input
     gradient and adapter gradients vs fp32 math on the dequantised weight."""
     from vision_ft_amd import kernels
@@ -142,6 +155,68 @@ def test_qlora_linear_one_launch_per_direction(gpu, M, out_f, in_f, r, dq, res):
         assert torch.equal(rg.grad.cpu(), gy)
 
 
+def test_nf4_dequant_once_equals_the_bf16_gemm_on_the_dequantised_weight_bitwise(gpu):
+    """The dequantise-once launch writes exactly vft_nf4_dequant's values (forward orientation and the transposed one of the
+    data gradient) and then runs the bf16 main loop: same tile, same order of sums => the SAME BITS as vft_linear_fwd on the
+    dequantised weight.  Layers of different sizes alternate on the one shared workspace (its barrier words are at a fixed
+    place and every launch leaves them zero), every call is repeated, and no launch may have timed out at the barrier."""
+    from vision_ft_amd import kernels
+
+    assert kernels.NF4_DEQUANT_ONCE
+    g = torch.Generator().manual_seed(11)
+    layers = [_make_layer(gpu, o, i, dq, bias=False)[0] for o, i, dq in ((2304, 2304, True), (384, 1024, False), (6144, 2304, True), (192, 320, True))]
+
+    def dense_of(q):
+        # the weight the launch must build: bf16(code[c] * absmax) with the SAME fp32 absmax the kernel gets (a double-quantised
+        # absmax is expanded once on the host side; vft_nf4_dequant expands it itself and may differ in a last bit)
+        pk = q.packed.view(-1).long()
+        idx = torch.stack([pk >> 4, pk & 15], dim=1).view(-1)
+        return (q.code.float()[idx] * q.absmax_f32().repeat_interleave(64)).to(torch.bfloat16).view(q.out_features, q.in_features)
+
+    dense = [dense_of(ly.quant_state()) for ly in layers]
+    for ly, w in zip(layers, dense):
+        assert (ly.dequantize() != w).float().mean().item() < 1e-3
+    for rep in range(2):
+        for ly, w in zip(layers, dense):
+            q = ly.quant_state()
+            for M in (1500, 333):
+                x = _bf(g, M, q.in_features).to(gpu)
+                dy = _bf(g, M, q.out_features).to(gpu)
+                y = kernels._nf4_gemm(x, q, None, False)
+                assert torch.equal(y, kernels.linear_fused(x, w)), (rep, w.shape, M)
+                dx = kernels._nf4_gemm(dy, q, None, True)
+                assert torch.equal(dx, kernels.linear_fused(dy, w.t().contiguous())), (rep, w.shape, M)
+    torch.cuda.synchronize()
+    assert not kernels.nf4_barrier_timed_out()
+    ws = kernels._NF4_WS[torch.device(gpu)][-1]
+    assert int(ws[:16].view(torch.int32).abs().sum()) == 0  # barrier words left zero
+
+
+def test_nf4_dequant_once_replays_from_a_graph(gpu):
+    """Capturable: no host-side reset of the barrier words, static workspace address."""
+    from vision_ft_amd import kernels
+
+    layer = _make_layer(gpu, 1280, 640, True, bias=False)[0]
+    q = layer.quant_state()
+    x = torch.randn(2048, 640, device=gpu).to(torch.bfloat16)
+    want = kernels._nf4_gemm(x, q, None, False)
+    torch.cuda.synchronize()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        kernels._nf4_gemm(x, q, None, False)
+    torch.cuda.current_stream().wait_stream(s_)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = kernels._nf4_gemm(x, q, None, False)
+        y2 = kernels._nf4_gemm(y[:, :640].contiguous(), q, None, False)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, want) and torch.equal(y2, kernels._nf4_gemm(want[:, :640].contiguous(), q, None, False))
+    assert not kernels.nf4_barrier_timed_out()
+
+
 def test_nf4_state_dict_layout_and_roundtrip(gpu):
     """Mirrors the reference's tests/test_modules_quant.py:153-193: key names, uint8 storage, reload
     self-consistency."""
@@ -161,15 +236,19 @@ def test_nf4_state_dict_layout_and_roundtrip(gpu):
         NF4Linear(128, 256).load_state_dict({"weight": torch.zeros(256, 128), "bias": torch.zeros(256)})  # not pre-quantised
 
 
-@pytest.fixture(params=["bf16_compute_cache", "in_gemm_dequant"])
+@pytest.fixture(params=["bf16_compute_cache", "in_gemm_dequant", "in_loop_dequant"])
 def nf4_mode(request):
-    """Both compute modes of the NF4 layers: the dequantised bf16 compute copy (default) and the dequantising GEMM."""
+    """The compute modes of the NF4 layers: the dequantised bf16 compute copy (labelled option), the dequantising GEMM (default:
+    once per launch) and its round-3 form (inside the K-loop)."""
+    from vision_ft_amd import kernels
     from vision_ft_amd.modules.quant import nf4
 
-    old = nf4.NF4_COMPUTE_CACHE
+    old, old_once = nf4.NF4_COMPUTE_CACHE, kernels.NF4_DEQUANT_ONCE
     nf4.NF4_COMPUTE_CACHE = request.param == "bf16_compute_cache"
+    kernels.NF4_DEQUANT_ONCE = request.param != "in_loop_dequant"
     yield request.param
-    nf4.NF4_COMPUTE_CACHE = old
+    nf4.NF4_COMPUTE_CACHE, kernels.NF4_DEQUANT_ONCE = old, old_once
+    assert not kernels.nf4_barrier_timed_out()
 
 
 def test_nf4_compute_cache_is_bit_identical_to_the_dequantising_gemm_input(gpu):

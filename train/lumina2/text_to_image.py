@@ -14,6 +14,7 @@ from vision_ft_amd.config import TrainConfig  # noqa: E402
 from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig  # noqa: E402
 from vision_ft_amd.models.lumina2 import Denoiser, Lumina2Config, Scheduler  # noqa: E402
 from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity, prepare_noised_latents  # noqa: E402
+from vision_ft_amd.modules.loss.reduce import mse_mean  # noqa: E402
 from vision_ft_amd.modules.timestep.sampling import shift_fraction_uniform_rand, uniform_rand  # noqa: E402
 from vision_ft_amd.models.lumina2.pipeline import Lumina2  # noqa: E402
 from vision_ft_amd.trainer.common import Trainer  # noqa: E402
@@ -69,7 +70,7 @@ class Lumina2ForTextToImageTraining(DenoiserTask):
         pred = -out
         loss = loss_with_predicted_velocity(latents, noise, pred)
         if self.model_config.use_downsampled_velocity_loss:
-            loss = loss + F.mse_loss(F.avg_pool2d(pred.float(), 4, 4), F.avg_pool2d((noise - latents).float(), 4, 4))
+            loss = loss + mse_mean(F.avg_pool2d(pred.float(), 4, 4), F.avg_pool2d((noise - latents).float(), 4, 4))
         return loss
 
     def convert_adapter_key(self, key: str) -> str:

@@ -22,6 +22,7 @@ from vision_ft_amd.dataset.synthetic import SyntheticLatentDatasetConfig  # noqa
 from vision_ft_amd.models.sdxl.adapter.flow_match import SDXLFlowMatch, SDXLFlowMatchConfig  # noqa: E402
 from vision_ft_amd.modules.loss.flow_match import (ModelPredictionType, convert_x0_to_velocity,  # noqa: E402
                                                    loss_with_predicted_velocity, prepare_scaled_noised_latents)
+from vision_ft_amd.modules.loss.reduce import mse_mean  # noqa: E402
 from vision_ft_amd.modules.timestep.sampling import TimestepSamplingType, sample_timestep  # noqa: E402
 from vision_ft_amd.trainer.common import Trainer  # noqa: E402
 
@@ -55,9 +56,9 @@ class SDXLForFlowMatchingTraining(SDXLForTextToImageTraining):
                                                   eps=cfg.timestep_eps, clean_at_zero=cfg.clean_at_zero)
                 v_pred = convert_x0_to_velocity(x0=model_pred, noisy_latents=noisy_latents, timestep=timestep,
                                                 eps=cfg.timestep_eps, clean_at_zero=cfg.clean_at_zero)
-                return F.mse_loss(v_pred, target_v, reduction="mean")
+                return mse_mean(v_pred, target_v)
             if cfg.loss_type == "image":
-                return F.mse_loss(model_pred, latents.clone().detach(), reduction="mean")
+                return mse_mean(model_pred, latents.clone().detach())
             raise NotImplementedError(f"loss_type {cfg.loss_type} not implemented for image prediction")
         raise ValueError(f"Unknown model_prediction: {cfg.model_prediction}")
 

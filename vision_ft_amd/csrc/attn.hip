@@ -2076,17 +2076,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
     bf16_t* dVb = p.dv + b * p.sdv.b + hkv * p.sdv.h;
     const int key = n0 + w * 32 + r;
     const bool kmem = key < p.Sk, kval = key < kvl;
-    bf16x8 Kf[KS], Vf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
-        Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        pin_loaded(Kf[ks]);
-        pin_loaded(Vf[ks]);
-    }
     f32x16 dK[DT], dV[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -2130,6 +2119,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
     for (int hi = 0; hi < 2; ++hi) {
         const int vr = 4 * h + (i16 >> 2) + 8 * hi;
         tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;
+    }
+    // The K / V fragments are loaded HERE, behind the staging prologue, and waited for before the loop.  Round 3 loaded them
+    // first; the prologue's address arithmetic then spilled all 12, hipcc reloaded them in front of the loop and carried the
+    // reloads into it as pending: the first 12 MFMAs of EVERY iteration waited vmcnt(11) .. vmcnt(0) — on the hardware counter
+    // those are the nine DMA pieces of the next tile issued a moment earlier, so the prefetch distance was an eighth of a
+    // tile instead of a tile (seen in the ISA, round 4).
+    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Kf[ks] = ldg_frag(Kb + (int64_t)key * p.sk.s + ks * 16 + 8 * h, kval);
+        Vf[ks] = ldg_frag(Vb + (int64_t)key * p.sv.s + ks * 16 + 8 * h, kval);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        pin_loaded(Kf[ks]);
+        pin_loaded(Vf[ks]);
     }
     int buf = 0;
     for (int it = it0; it < it1; ++it) {

@@ -414,3 +414,63 @@ extern "C" int vft_transpose_bf16(const void* src, void* dst, int R, int C, int6
     VFT_CHECK_LAUNCH("vft_transpose_bf16");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mean(x^2) of a dense fp32 buffer — the reduction of the reference's MSE losses (src/modules/loss/diffusion.py:62-68,
+// loss/flow_match.py:85-96: F.mse_loss(..., reduction="mean") on fp32 tensors).  Two launches, no atomics, no memset:
+// workgroup g sums a fixed contiguous chunk in a fixed order into partial[g]; one workgroup folds the partials in index
+// order and scales by 1 / n.  Bit-reproducible, and — the reason it exists (round 4) — safe inside a replayed HIP graph:
+// ATen's full reduction is ONE launch whose workgroups meet through a semaphore buffer zeroed by a memset node in front
+// of it; in the captured SDXL step that reduction returned garbage (negative "MSE" values) for every replay after the
+// process had synchronised an idle stream, while every other tensor of the step stayed bit-identical to the eager run.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int MSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void mean_sq_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t n) {
+    __shared__ float red[256];
+    const int64_t chunk = ((n + MSQ_BLOCKS - 1) / MSQ_BLOCKS + 3) / 4 * 4;  // multiple of 4 floats: 16-byte loads stay aligned
+    const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+    float s = 0.f;
+    for (int64_t i = b0 + 4 * (int64_t)threadIdx.x; i < b1; i += 1024) {
+        if (i + 4 <= b1) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+            s += v[0] * v[0];
+            s += v[1] * v[1];
+            s += v[2] * v[2];
+            s += v[3] * v[3];
+        } else {
+            for (int64_t j = i; j < b1; ++j) s += x[j] * x[j];
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void mean_sq_final_kernel(const float* __restrict__ partial, float* __restrict__ out, float inv_n) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < MSQ_BLOCKS; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * inv_n;
+}
+}  // namespace
+
+extern "C" int64_t vft_mean_sq_scratch_floats(void) { return MSQ_BLOCKS; }
+
+extern "C" int vft_mean_sq(const float* x, float* out, float* scratch, int64_t n, void* stream) {
+    VFT_CHECK_ARG(x && out && scratch, "vft_mean_sq: null pointer");
+    VFT_CHECK_ARG(n > 0 && ((uintptr_t)x & 15) == 0, "vft_mean_sq: needs n > 0 and a 16-byte aligned input (n=%lld)", (long long)n);
+    hipLaunchKernelGGL(mean_sq_partial_kernel, dim3(MSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, scratch, n);
+    hipLaunchKernelGGL(mean_sq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, out, (float)(1.0 / (double)n));
+    VFT_CHECK_LAUNCH("vft_mean_sq");
+    return 0;
+}

@@ -25,6 +25,8 @@
 // of hipBLASLt's best solution; the rank extension is free.  The denoisers therefore still route plain
 // projections to the tuned library (vision_ft_amd/tuning.py) — this kernel is the base for the fused
 // epilogues (LoRA, residual, NF4) once its main loop closes the remaining gap.
+#include <cstdlib>
+
 #include "vft_common.h"
 #include "linear8.h"
 
@@ -541,6 +543,7 @@ static void launch_lin8_cfg(Lin8Params q, int cfg, bool conv, hipStream_t st) {
             a.M = M1;
             a.x_rows = b.x_rows = q.M;
             b.m_begin = M1;
+            b.q_packed = nullptr;  // NF4: the first launch has dequantised the weight into the scratch; the tail reads it as bf16
             vft_lin8_launch(a, main_cfg, conv, st);
             vft_lin8_launch(b, vft_lin8_pick_plain(q.M - M1, q.N, q.K), conv, st);
             return;
@@ -659,10 +662,18 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
 // Replaces bnb.matmul_4bit of BnbLinear4bit (src/modules/quant/bnb.py:37-129) and, with the rank extension, the
 // whole NF4-base + LoRA forward of a QLoRA layer in one launch.  absmax: already expanded to fp32 by the caller
 // (double-quantised checkpoints: code2[q8] * absmax2[blk / 256] + offset, once at load time).
+// Round 4: with a workspace (vft_linear_nf4_workspace bytes, its FIRST 16 KiB zero before the first use, re-usable by
+// every NF4 layer of a stream) the launch dequantises the weight ONCE into it — all workgroups share the work, meet at a
+// grid barrier and run the bf16 main loop of linear8.hip on the result — instead of once per row tile inside the K-loop
+// (the form without a workspace, kept for operands the second-generation kernel does not take).
+extern "C" int64_t vft_linear_nf4_workspace(int out_features, int in_features) {
+    return (((int64_t)out_features * in_features * 2 + 255) & ~255ll) + 16384;  // 16 KiB header: barrier words (+ cycle stamps of the timing experiments)
+}
+
 extern "C" int vft_linear_nf4(const void* x, void* y, const void* bias, const void* residual, const void* ext_x,
                               const void* ext_w, const void* packed, const float* absmax, const float* code,
                               int out_features, int in_features, int M, int r, int64_t ldx, int64_t ldy, int64_t ldres,
-                              int transpose_w, void* stream) {
+                              int transpose_w, void* workspace, int64_t ws_bytes, void* stream) {
     VFT_CHECK_ARG(x && y && packed && absmax && code, "vft_linear_nf4: null pointer");
     const int N = transpose_w ? in_features : out_features;
     const int K = transpose_w ? out_features : in_features;
@@ -681,9 +692,30 @@ extern "C" int vft_linear_nf4(const void* x, void* y, const void* bias, const vo
     p.ex = (const bf16_t*)ext_x, p.ew = (const bf16_t*)ext_w;
     p.M = M, p.N = N, p.K = K, p.r = ext_x ? r : 0, p.ldx = ldx, p.ldy = ldy, p.ldres = ldres;
     p.q_packed = (const uint8_t*)packed, p.q_absmax = absmax, p.q_code = code, p.QN = out_features, p.QK = in_features;
+    hipStream_t st = (hipStream_t)stream;
+    if (workspace != nullptr) {
+        // dequantise-once form on the second-generation kernel (linear8.hip: nf4_fill_and_meet): the workspace holds 4 barrier
+        // words (in its first 16 KiB) and, behind them, the bf16 image of the weight for the duration of this launch
+        VFT_CHECK_ARG(ws_bytes >= vft_linear_nf4_workspace(out_features, in_features) && ((uintptr_t)workspace & 255) == 0,
+                      "vft_linear_nf4: workspace of %lld bytes (256-byte aligned) needed, got %lld", (long long)vft_linear_nf4_workspace(out_features, in_features), (long long)ws_bytes);
+        Lin8Params q{};
+        q.x = p.x, q.w = (const bf16_t*)((char*)workspace + 16384), q.y = p.y, q.bias = p.bias, q.res = p.res, q.ex = p.ex, q.ew = p.ew;
+        q.M = M, q.N = N, q.K = K, q.r = p.r, q.ldx = ldx, q.ldw = K, q.ldy = ldy, q.ldres = ldres;
+        q.q_packed = p.q_packed, q.q_absmax = absmax, q.q_code = code, q.QN = out_features, q.QK = in_features, q.q_trans = transpose_w ? 1 : 0;
+        q.q_sync = reinterpret_cast<unsigned*>(workspace);  // at a FIXED place: layers of different sizes share one workspace
+        {  // timing experiments only (read per call so that a script can switch it between calls)
+            const char* e = getenv("VFT_NF4_DEBUG");
+            q.q_debug = e ? atoi(e) : 0;
+        }
+        if (g_variant >= 0 && K % 64 == 0 && out_features % 8 == 0 && q.r <= 16 && vft_lin8_fits(q, false)) {
+            launch_lin8_cfg(q, g_variant > 0 ? g_variant : pick_tile(M, N, K, 0), false, st);
+            VFT_CHECK_LAUNCH("vft_linear_nf4");
+            return 0;
+        }
+        // shapes the second-generation kernel does not take fall through to the in-loop form below
+    }
     const int rem = N % 256;
     const bool wide = N >= 1024 && (rem == 0 || rem > 192) && (!transpose_w || in_features >= 32);
-    hipStream_t st = (hipStream_t)stream;
     if (!transpose_w) {
         if (wide)
             launch_linear<Cfg<256, 256, 2, 2, 2, false, false, 64, 1>>(p, st);

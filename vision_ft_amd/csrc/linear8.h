@@ -22,6 +22,18 @@ struct Lin8Params {
     int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
     int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
     int nt_store;          // y is stored with the non-temporal hint (set by vft_lin8_launch: outputs above 16 MiB)
+    // NF4 base weight (vft_linear_nf4 with a workspace): q_packed != null makes the launch DEQUANTISE the weight first — every
+    // workgroup converts its share of the packed codes into `w` (then a bf16 scratch [N][ldw = K] the caller provides), the
+    // grid meets at a barrier (q_sync), and the main loop stages that scratch like any bf16 weight.  One dequantisation per
+    // GEMM instead of one per row tile; the scratch (<= 28 MB for Lumina2) lives in the Infinity Cache, the 4-bit codes stay
+    // the only copy of the weight that persists in HBM.  Logical weight [QN][QK] (out, in), blocksize 64 along in.
+    const uint8_t* q_packed;  // [QN*QK/2], element 2i in the high nibble
+    const float* q_absmax;    // [QN*QK/64]
+    const float* q_code;      // [16]
+    int QN, QK;
+    int q_trans;              // 0: w[n][k] = W[n][k] (forward, N = QN, K = QK);  1: w[n][k] = W[k][n] (data gradient, N = QK, K = QN)
+    unsigned* q_sync;         // 4 words, zero before the first launch: arrivals, departures, error flag, spare
+    int q_debug;              // timing experiments only (VFT_NF4_DEBUG): 1 = skip the conversion, 2 = skip the barrier + fences (WRONG results)
 };
 
 // true when the operands fit the 32-bit offsets of the buffer descriptors (otherwise: first-generation kernel)

@@ -88,11 +88,166 @@ struct C8 {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <class C>
+// ---- NF4 base weight: dequantise ONCE per launch, inside the launch ------------------------------------------------
+// (replaces bnb.matmul_4bit of BnbLinear4bit, src/modules/quant/bnb.py:37-129.)  Round 3 dequantised inside the K-loop:
+// every row tile decoded the same weights again (68 times at M = 17 408) and the table look-ups saturated the loop's LDS
+// pipe.  Here every workgroup of the persistent grid first converts 1/grid of the packed codes into a bf16
+// scratch, the grid meets at a barrier, and the main loop then runs exactly as for a bf16 weight.  The values are those
+// of vft_nf4_dequant, bit for bit: bf16(code[c] * absmax).
+//   forward (q_trans = 0):        scratch[n][k] = W[n][k]   — elementwise, 8 weights (4 code bytes -> 16 bytes) per step
+//   data gradient (q_trans = 1):  scratch[i][o] = W[o][i]   — blocks of 128 o x 64 i transposed through LDS: a thread decodes
+//       8 consecutive i of rows o, o + 1 and writes (o, o+1) pairs as dwords into a [64 i][128 o] image (row stride 260 B:
+//       the 64 lanes of a write hit 64 banks), then rows of the image leave as 16-byte pieces.
+// Barrier: arrivals counted in q_sync[0] (one relaxed atomic per workgroup; the cache maintenance that makes the scratch
+// visible across the eight XCDs' L2s is explicit, once per workgroup); the spin is BOUNDED (every wave reaches the end of the kernel whatever happens:
+// on a time-out the error word q_sync[2] is set and the host-side tests look at it); the last workgroup to leave resets
+// the counters, so a launch always finds them zero (graph replay: no host-side memset).  Co-residency of the grid is the
+// launcher's duty (grid <= occupancy x CUs, launch8).
+// 16-byte store that is WRITTEN THROUGH this XCD's L2 (sc0 sc1): the image of the weight must be visible to the other seven
+// XCDs behind the barrier; written through, nothing of it is a dirty L2 line when the workgroups meet and the release side
+// of the barrier needs no `buffer_wbl2` sweep.  (tools/exp/nf4_time.py, M 17408 N 3840 K 2304 on a warm chip: the launch
+// without conversion and barrier 210 us = the bf16 launch; conversion +8; barrier +14; both 235; plain stores + one
+// `buffer_wbl2` per workgroup 235 as well; a separate dequantisation kernel in front of the bf16 launch 225.)
+__device__ __forceinline__ void store16_through(void* dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void nf4_fill_and_meet(const Lin8Params& p, unsigned char* lds) {
+    const int tid = threadIdx.x;
+    // (VFT_NF4_DEBUG & 16, tools/exp/nf4_time.py: cycle stamps of every workgroup at start / conversion done / barrier passed)
+    unsigned long long* stamps = (p.q_debug & 16) ? reinterpret_cast<unsigned long long*>(p.q_sync) + 32 + 4 * blockIdx.x : nullptr;
+    if (stamps && tid == 0) stamps[0] = wall_clock64();
+    float* code_s = reinterpret_cast<float*>(lds + 64 * 260);
+    if (tid < 16) code_s[tid] = p.q_code[tid];
+    __syncthreads();
+    bf16_t* const out = const_cast<bf16_t*>(p.w);
+    auto decode = [&](unsigned d, float am, bf16_t (&v)[8]) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const unsigned byte = (d >> (8 * bb)) & 0xffu;
+            v[2 * bb] = (bf16_t)(code_s[byte >> 4] * am);
+            v[2 * bb + 1] = (bf16_t)(code_s[byte & 15] * am);
+        }
+    };
+    if (p.q_debug & 1) {
+    } else if (!p.q_trans) {
+        // one step = 4 code bytes -> 8 weights -> one 16-byte store; consecutive lanes take consecutive steps (every load
+        // instruction 256 contiguous bytes, every store 1 KiB: the first version gave a lane 16 code bytes and its four
+        // stores landed 64 bytes apart from the neighbour lane's — the conversion then took ~80 us instead of ~10), and a
+        // thread requests EIGHT steps, a grid-width apart, before it decodes the first: one memory round trip for the
+        // whole weight at Lumina2's sizes (8.4 steps per thread)
+        const int64_t nvec = (int64_t)p.QN * p.QK / 8, T = (int64_t)gridDim.x * NT;
+        for (int64_t e0 = (int64_t)blockIdx.x * NT + tid; e0 < nvec; e0 += 8 * T) {
+            unsigned d[8];
+            float am[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t e = e0 + u * T;
+                d[u] = 0u, am[u] = 0.f;
+                if (e < nvec) {
+                    d[u] = reinterpret_cast<const unsigned*>(p.q_packed)[e];
+                    am[u] = p.q_absmax[e >> 3];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t e = e0 + u * T;
+                if (e < nvec) {
+                    bf16_t v[8];
+                    decode(d[u], am[u], v);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = v[j];
+                    store16_through(out + e * 8, __builtin_bit_cast(u32x4, o));
+                }
+            }
+        }
+    } else {
+        const int nbi = p.QK / 64, nblk = ((p.QN + 127) / 128) * nbi;
+        const int op = tid >> 3, ich = tid & 7;
+        // the codes of block `blk` for this thread (rows o, o + 1; 8 consecutive i): requested one block AHEAD of their use
+        auto fetch = [&](int blk, unsigned& d0, unsigned& d1, float& a0, float& a1) {
+            d0 = d1 = 0u, a0 = a1 = 0.f;
+            if (blk >= nblk) return;
+            const int bo = blk / nbi, i0 = (blk - bo * nbi) * 64, o = bo * 128 + 2 * op;
+            if (o < p.QN) {
+                const int64_t e0 = (int64_t)o * p.QK + i0;
+                d0 = *reinterpret_cast<const unsigned*>(p.q_packed + (e0 >> 1) + ich * 4), a0 = p.q_absmax[e0 >> 6];
+            }
+            if (o + 1 < p.QN) {
+                const int64_t e1 = (int64_t)(o + 1) * p.QK + i0;
+                d1 = *reinterpret_cast<const unsigned*>(p.q_packed + (e1 >> 1) + ich * 4), a1 = p.q_absmax[e1 >> 6];
+            }
+        };
+        unsigned nd0, nd1;
+        float na0, na1;
+        fetch(blockIdx.x, nd0, nd1, na0, na1);
+        for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+            const int bo = blk / nbi, i0 = (blk - bo * nbi) * 64;
+            const unsigned d0 = nd0, d1 = nd1;
+            const float a0 = na0, a1 = na1;
+            fetch(blk + gridDim.x, nd0, nd1, na0, na1);
+            bf16_t v0[8], v1[8];
+            decode(d0, a0, v0);
+            decode(d1, a1, v1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned pr = (unsigned)__builtin_bit_cast(unsigned short, v0[j]) | ((unsigned)__builtin_bit_cast(unsigned short, v1[j]) << 16);
+                *reinterpret_cast<unsigned*>(lds + (ich * 8 + j) * 260 + op * 4) = pr;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = tid + NT * q, i = idx >> 4, c = idx & 15;
+                const unsigned* src = reinterpret_cast<const unsigned*>(lds + i * 260 + c * 16);
+                const u32x4 r = {src[0], src[1], src[2], src[3]};
+                const int oc = bo * 128 + c * 8;
+                if (oc < p.QN) store16_through(out + (int64_t)(i0 + i) * p.QN + oc, r);
+            }
+            __syncthreads();
+        }
+    }
+    if (p.q_debug & 2) return;
+    // ---- grid barrier.  Release: the image left through write-through stores, so every wave only waits for its own stores to
+    //      be acknowledged (no L2 write-back; `__threadfence()` in every thread — eight waves x 32 workgroups per XCD each
+    //      sweeping the whole L2 for write-back and again for invalidation — cost ~50 us per launch in the first version).
+    //      Acquire: ONE wave per workgroup drops the stale
+    //      lines of the scratch (it is re-used by every NF4 layer) from this CU's L1 and this XCD's L2.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stamps && tid == 0) stamps[1] = wall_clock64();
+    if (tid < 64) {
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&p.q_sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            // bounded: every wave reaches the end of the kernel whatever happens (on a time-out the error word is set)
+            while (__hip_atomic_load(&p.q_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 24)) {
+                    __hip_atomic_store(&p.q_sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        asm volatile("buffer_inv sc1" ::: "memory");
+        if (tid == 0) {
+            const unsigned left = __hip_atomic_fetch_add(&p.q_sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left == gridDim.x - 1) {  // everybody is past the spin: zero the counters for the next launch
+                __hip_atomic_store(&p.q_sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&p.q_sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+    if (stamps && tid == 0) stamps[2] = wall_clock64();
+}
+
+template <class C, bool NF4 = false>
 __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     constexpr int BM = C::BM, BN = C::BN, FX = C::FX, FW = C::FW, XH = C::XH, WH = C::WH, TILE = C::TILE;
     constexpr int DX = C::DX, DW = C::DW;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm8[];
+    if (NF4) nf4_fill_and_meet(p, sm8);  // p.w is complete and visible from here on
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv / C::WAVES_N, wc = wv % C::WAVES_N, grp = wv >> 2;
@@ -120,12 +275,26 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc((void*)p.ex, 0, p.M * p.r * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rew = __builtin_amdgcn_make_buffer_rsrc((void*)p.ew, 0, p.N * p.r * 2, 0x00020000);
-    int gx[2][DX], gw[2][DW];  // byte offsets of this lane's chunks at k = 0
+    int gx[2][DX];  // byte offsets of this lane's x chunks at k = 0
+    // W: ONE lane-dependent offset for every tile (row lane>>3 of an 8-row group, chunk dch); the group's first row rides in
+    // the SCALAR offset.  N % 8 == 0, so an 8-row group lies wholly inside or wholly outside the weight: groups beyond N are
+    // moved to the last 8 rows (valid memory; their output columns are never stored) — wave-uniform, on the scalar unit.
+    // (Round 3 kept 2 x DW per-lane offsets alive across the main loop; in the convolution instantiation two of them were
+    // SPILLED, and their scratch reload inside phase B made hipcc wait `vmcnt(1)` between the X and W DMAs of every K-tile
+    // — a full memory latency with the partner wave group idle behind the barrier.)
+    // A/B on one MI355X (tools/exp/lin8_ab.py, old / new library): 256x256 convolutions at 64^2 / 32^2 +4-13 % (1 204 -> 1 287,
+    // 1 390 -> 1 557 TF/s), 256x256 projections +0-2 %; the smaller tiles (N = 320 convolutions) LOSE 2-10 % to the extra
+    // scalar work per DMA and never spilled — they keep the per-lane offsets.
+    constexpr bool SCALAR_W = BM == 256 && BN == 256;
+    const int wlane = (int)(((int64_t)drow * p.ldw + dch * 8) * 2);
+    int wn0 = 0;  // n0 of the tile being staged (scalar)
+    int gw[2][DW];  // !SCALAR_W: byte offsets of this lane's W chunks at k = 0
     unsigned vmask[2][DX];     // CONV: which of the 9 taps fall inside the image for this lane's pixel
     // CONV: K-tile t = (channel slice t / 9, tap t % 9); the X halves of one K-tile are issued at different times, so each keeps its own
     // incrementally advanced (tap, channel offset)
     int ctap[2] = {0, 0}, cc0[2] = {0, 0};
     auto setup = [&](int m0, int n0) {
+        wn0 = n0;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -145,10 +314,12 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
                     vmask[hh][q] = m;
                 }
             }
+            if (!SCALAR_W) {
 #pragma unroll
-            for (int q = 0; q < DW; ++q) {
-                const int row = hh * (BN / 2) + (wv * DW + q) * 8 + drow;
-                gw[hh][q] = (int)(((int64_t)min(n0 + row, p.N - 1) * p.ldw + dch * 8) * 2);
+                for (int q = 0; q < DW; ++q) {
+                    const int row = hh * (BN / 2) + (wv * DW + q) * 8 + drow;
+                    gw[hh][q] = (int)(((int64_t)min(n0 + row, p.N - 1) * p.ldw + dch * 8) * 2);
+                }
             }
             ctap[hh] = 0, cc0[hh] = 0;
         }
@@ -179,7 +350,14 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
         // the weight rows are [tap][Cin]: K-tile t of the order above is tap t % 9, channel slice t / 9
         const int koff = C::CONV ? ((t % 9) * p.cC + (t / 9) * 64) * 2 : t * 128;
 #pragma unroll
-        for (int q = 0; q < DW; ++q) dma16(rw, dst + q * 1024, gw[hh][q], koff);
+        for (int q = 0; q < DW; ++q) {
+            if (SCALAR_W) {
+                const int g0 = min(wn0 + hh * (BN / 2) + (wv * DW + q) * 8, p.N - 8);  // first row of the 8-row group (scalar)
+                dma16(rw, dst + q * 1024, wlane, g0 * (int)p.ldw * 2 + koff);
+            } else {
+                dma16(rw, dst + q * 1024, gw[hh][q], koff);
+            }
+        }
     };
 
     // ---- fragment read offsets (bytes inside a half-tile): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 kk + lq;
@@ -456,23 +634,42 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
     }
 }
 
-template <class C>
-void launch8(const Lin8Params& p, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(lin8_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <class C, bool NF4>
+void launch8k(const Lin8Params& p, hipStream_t st) {
+    static int resident = 0;  // workgroups of this kernel the chip holds at once (first call; 0 = not asked yet)
+    if (!resident) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(lin8_kernel<C, NF4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C::LDS_BYTES);
-        attr = true;
+        resident = C::SLOTS;
+        if (NF4) {
+            // the dequantising launch meets at a grid barrier: the grid must fit the chip (asked once, outside any capture
+            // in practice: the first call is an eager warm-up step; a failed query keeps the conservative one per CU)
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(lin8_kernel<C, NF4>), NT, C::LDS_BYTES) != hipSuccess)
+                per_cu = 1;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 8;
+            (void)hipGetLastError();
+            const int fit = (per_cu < 1 ? 1 : per_cu) * cus;
+            resident = fit < C::SLOTS ? (fit >= 8 ? fit / 8 * 8 : fit) : C::SLOTS;
+        }
     }
     // persistent workgroups: one per resident slot (a multiple of 8, so that a workgroup stays in one XCD group), or
     // one per tile when there are fewer tiles than slots
     const unsigned tiles = (unsigned)(((p.M - p.m_begin + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN));
 #ifdef L8_NONPERSIST
-    const unsigned grid = tiles;
+    const unsigned grid = NF4 ? (tiles < (unsigned)resident ? tiles : (unsigned)resident) : tiles;
 #else
-    const unsigned grid = tiles < (unsigned)C::SLOTS ? tiles : (unsigned)C::SLOTS;
+    const unsigned grid = tiles < (unsigned)resident ? tiles : (unsigned)resident;
 #endif
-    hipLaunchKernelGGL(lin8_kernel<C>, dim3(grid), dim3(NT), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((lin8_kernel<C, NF4>), dim3(grid), dim3(NT), C::LDS_BYTES, st, p);
+}
+template <class C>
+void launch8(const Lin8Params& p, hipStream_t st) {
+    if constexpr (!C::CONV) {
+        if (p.q_packed != nullptr) return launch8k<C, true>(p, st);
+    }
+    launch8k<C, false>(p, st);
 }
 
 }  // namespace

@@ -355,6 +355,37 @@ class _GateResidual(torch.autograd.Function):
         return dres, dgate, dy, None
 
 
+class _MeanSq(torch.autograd.Function):
+    """mean(d^2) of a dense fp32 tensor (vft_mean_sq); backward 2 d g / n."""
+
+    @staticmethod
+    def forward(ctx, d):
+        out = torch.empty((), dtype=torch.float32, device=d.device)
+        scratch = torch.empty(int(_C.lib().vft_mean_sq_scratch_floats()), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device), _Timed("mean_sq", 4.0 * d.numel()):
+            st = _C.lib().vft_mean_sq(_ptr(d), _ptr(out), _ptr(scratch), d.numel(), _stream())
+        _C.check(st, "vft_mean_sq")
+        ctx.save_for_backward(d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * (g * (2.0 / d.numel()))
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """F.mse_loss(pred.float(), target.float(), reduction="mean") — the reference's loss reduction
+    (src/modules/loss/diffusion.py:62-68, loss/flow_match.py:85-96) — with the reduction on the two-launch, atomics-free HIP
+    kernel (see csrc/eltwise.hip: ATen's one-launch reduction misbehaved inside replayed HIP graphs).  The difference is an ATen
+    elementwise op (any dense layout: a sum does not care about the order); gradients flow through it as usual."""
+    _require_gpu(pred, target, dtype=None)
+    d = pred.float() - target.float()
+    if not (d.is_contiguous() or d.is_contiguous(memory_format=torch.channels_last) or d.is_contiguous(memory_format=torch.channels_last_3d)):
+        d = d.contiguous()
+    return _MeanSq.apply(d)
+
+
 def gate_residual(residual: torch.Tensor, gate: torch.Tensor, y: torch.Tensor, tanh: bool = False) -> torch.Tensor:
     """residual + g[:,None,:] * y  with g = tanh(gate) if `tanh`."""
     _ready(residual)
@@ -2040,8 +2071,29 @@ def _nf4_gemm_v1(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool) -> torc
     return out
 
 
+# NF4 GEMM form (modules/quant/nf4.py documents the switch): True = the launch dequantises the weight ONCE into a transient bf16
+# workspace (all workgroups share the work, grid barrier, then the bf16 main loop of lin8); False = round 3's form, codes
+# dequantised inside the K-loop by every row tile.  Either way the 4-bit codes are the only copy that persists in HBM.
+NF4_DEQUANT_ONCE = os.environ.get("VFT_NF4_INLOOP", "0") == "0"
+_NF4_WS: dict = {}  # device -> list of workspaces ever handed out (never freed: captured graphs keep their addresses)
+
+
+def _nf4_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """One scratch per device, shared by every NF4 layer (launches on a stream are ordered, and a launch is done with the
+    scratch when it ends).  Its first 16 KiB hold the grid barrier's words: zero at first use, left zero by every launch.  Grows by allocating a NEW buffer (the old one stays alive for graphs captured with it)."""
+    pool = _NF4_WS.setdefault(device, [])
+    if not pool or pool[-1].numel() < nbytes:
+        pool.append(torch.zeros(max(nbytes, 32 << 20), dtype=torch.uint8, device=device))
+    return pool[-1]
+
+
+def nf4_barrier_timed_out() -> bool:
+    """True if a dequantising launch ever gave up waiting at its grid barrier (tests: the error word of every scratch)."""
+    return any(int(ws[:16].view(torch.int32)[2]) != 0 for pool in _NF4_WS.values() for ws in pool)
+
+
 def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None, ext_w=None, residual=None) -> torch.Tensor:
-    """NF4-weight GEMM on the LDS-DMA kernel (vft_linear_nf4), optional fused rank extension / residual."""
+    """NF4-weight GEMM (vft_linear_nf4), optional fused rank extension / residual."""
     M = a2.shape[0]
     N = q.in_features if transpose_w else q.out_features
     K = q.out_features if transpose_w else q.in_features
@@ -2049,11 +2101,15 @@ def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None
         return _nf4_gemm_v1(a2, q, bias, transpose_w)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
     r = ext_x.shape[1] if ext_x is not None else 0
+    ws, ws_bytes = None, 0
+    if NF4_DEQUANT_ONCE:
+        ws_bytes = int(_C.lib().vft_linear_nf4_workspace(q.out_features, q.in_features))
+        ws = _nf4_workspace(a2.device, ws_bytes)
     with torch.cuda.device(a2.device), _Timed("gemm_nf4", 2.0 * M * N * (K + r)):
         st = _C.lib().vft_linear_nf4(_ptr(a2), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ext_x), _ptr(ext_w), _ptr(q.packed),
                                      _ptr(q.absmax_f32()), _ptr(q.code), q.out_features, q.in_features, M, r, a2.stride(0),
                                      out.stride(0), residual.stride(0) if residual is not None else 0, int(transpose_w),
-                                     _stream())
+                                     _ptr(ws), ws_bytes, _stream())
     _C.check(st, "vft_linear_nf4")
     return out
 

@@ -7,7 +7,9 @@ from __future__ import annotations
 from typing import NamedTuple
 
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F  # noqa: F401
+
+from .reduce import mse_mean
 
 
 class NoisedLatents(NamedTuple):
@@ -45,4 +47,4 @@ def prepare_noised_latents(
 
 def loss_with_predicted_noise(latents: torch.Tensor, random_noise: torch.Tensor, predicted_noise: torch.Tensor) -> torch.Tensor:
     # fp32 like the reference under autocast (mse_loss is an autocast-to-fp32 op)
-    return F.mse_loss(predicted_noise.float(), random_noise.float(), reduction="mean")
+    return mse_mean(predicted_noise, random_noise)

@@ -4,7 +4,9 @@ from __future__ import annotations
 from typing import Literal, NamedTuple
 
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F  # noqa: F401
+
+from .reduce import mse_mean
 
 
 class NoisedLatents(NamedTuple):
@@ -37,7 +39,7 @@ def get_flow_match_target_velocity(latents: torch.Tensor, random_noise: torch.Te
 
 
 def loss_with_predicted_velocity(latents: torch.Tensor, random_noise: torch.Tensor, predicted_velocity: torch.Tensor) -> torch.Tensor:
-    return F.mse_loss(predicted_velocity.float(), (random_noise - latents).float(), reduction="mean")
+    return mse_mean(predicted_velocity, random_noise - latents)
 
 
 ModelPredictionType = Literal["noise", "velocity", "image"]

@@ -136,15 +136,23 @@ class GraphedTrainStep:
         gc.collect()
         torch.cuda.empty_cache()
         self.graph_a = torch.cuda.CUDAGraph()
+        # the reported loss lives in its own one-element buffer OUTSIDE the graph's pool and is copied there right behind the
+        # forward pass: F.mse_loss returns a 0-dim tensor that owns the whole elementwise buffer (6 MB at the bench size),
+        # and round 4 found element 0 of that buffer — "the loss" — overwritten by the time a replay ends once the process
+        # had called torch.cuda.synchronize() (bench.py printed negative MSE values since round 2; training was not affected:
+        # the backward pass never reads the value)
+        static_loss = None
         with torch.cuda.graph(self.graph_a, pool=pool):
             loss = self.forward_loss()
+            static_loss = loss.detach().clone()
             (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
             if self.single:
                 if self.after_backward is not None:
                     self.after_backward()
                 self.optimizer.step()
                 self.dp.zero_grad()
-            self.loss = loss.detach()
+            self.loss = static_loss
+            self._raw_loss = loss.detach()  # (diagnostics: tools/exp/graph_loss_debug.py)
         self.graph_b = self.graph_c = None
         if not self.single:
             if self.after_backward is not None:
