@@ -273,7 +273,7 @@ int vft_gate_residual(const void* residual, const void* gate, const void* y, voi
  *     (which stays in the 256 MB Infinity Cache: <= 28 MB for Lumina2's largest layer).  Bit-identical to vft_linear_fwd on
  *     vft_nf4_dequant's output.  The workspace (vft_linear_nf4_workspace bytes, 256-byte aligned) belongs to the caller, may
  *     be shared by every NF4 layer of a stream, and its FIRST 16 KiB (barrier words) must be zero before the first
- *     launch; every launch leaves them zero (graph replay needs no memset).  Word 2 is an error flag: a launch that could
+ *     launch; launches only advance them (graph replay needs no memset).  Word 2 is an error flag: a launch that could
  *     not assemble its grid at the barrier within a bounded wait sets it instead of hanging.
  *   workspace == NULL, or a shape the second-generation kernel does not take (K % 64 != 0, r = 32, operands >= 2 GiB):
  *     dequantisation in the staging threads of the first-generation kernel's K-loop (round 1-3).

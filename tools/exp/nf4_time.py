@@ -61,11 +61,11 @@ for out_f, in_f in [(3840, 2304), (2304, 2304), (6144, 2304), (2304, 6144)]:
     for _ in range(3):
         kernels._nf4_gemm(x, qs, None, False)
     torch.cuda.synchronize()
-    st = ws[256:256 + 256 * 32].view(torch.int64).view(256, 4).cpu().double()
+    st = ws[4096:4096 + 256 * 32].view(torch.int64).view(256, 4).cpu().double()
     t0 = st[:, 0].min()
     tick = 0.01  # wall_clock64: 100 MHz
     print(f"   stamps (us after the first start): start max {float((st[:,0]-t0).max())*tick:.1f} | conversion done: min {float((st[:,1]-t0).min())*tick:.1f} median {float((st[:,1]-t0).median())*tick:.1f} max {float((st[:,1]-t0).max())*tick:.1f} | barrier passed: min {float((st[:,2]-t0).min())*tick:.1f} max {float((st[:,2]-t0).max())*tick:.1f}")
-    ws[256:16384].zero_()
+    ws[4096:16384].zero_()
     os.environ["VFT_NF4_DEBUG"] = "0"
     img = ws[16384:16384 + out_f * in_f * 2].view(torch.bfloat16).view(out_f, in_f)
     def two():

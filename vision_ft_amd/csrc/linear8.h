@@ -32,7 +32,8 @@ struct Lin8Params {
     const float* q_code;      // [16]
     int QN, QK;
     int q_trans;              // 0: w[n][k] = W[n][k] (forward, N = QN, K = QK);  1: w[n][k] = W[k][n] (data gradient, N = QK, K = QN)
-    unsigned* q_sync;         // 4 words, zero before the first launch: arrivals, departures, error flag, spare
+    unsigned* q_sync;         // header of the workspace, zero before the first launch: [0] launch counter, [2] error flag,
+                              // [64 + 16 c] arrival word of workgroup class c (8 classes); [128 ...] cycle stamps (experiments)
     int q_debug;              // timing experiments only (VFT_NF4_DEBUG): 1 = skip the conversion, 2 = skip the barrier + fences (WRONG results)
 };
 

@@ -98,11 +98,11 @@ struct C8 {
 //   data gradient (q_trans = 1):  scratch[i][o] = W[o][i]   — blocks of 128 o x 64 i transposed through LDS: a thread decodes
 //       8 consecutive i of rows o, o + 1 and writes (o, o+1) pairs as dwords into a [64 i][128 o] image (row stride 260 B:
 //       the 64 lanes of a write hit 64 banks), then rows of the image leave as 16-byte pieces.
-// Barrier: arrivals counted in q_sync[0] (one relaxed atomic per workgroup; the cache maintenance that makes the scratch
-// visible across the eight XCDs' L2s is explicit, once per workgroup); the spin is BOUNDED (every wave reaches the end of the kernel whatever happens:
-// on a time-out the error word q_sync[2] is set and the host-side tests look at it); the last workgroup to leave resets
-// the counters, so a launch always finds them zero (graph replay: no host-side memset).  Co-residency of the grid is the
-// launcher's duty (grid <= occupancy x CUs, launch8).
+// Barrier: one relaxed atomic per workgroup into one of eight arrival words (q_sync[64 + 16 c]) that are never reset, a
+// launch counter (q_sync[0]) that workgroup 0 advances; the cache maintenance that makes the image visible across the eight
+// XCDs' L2s is explicit, once per workgroup; the spin is BOUNDED (every wave reaches the end of the kernel whatever
+// happens: on a time-out the error word q_sync[2] is set and the host-side tests look at it).  No host-side memset between
+// launches (graph replay).  Co-residency of the grid is the launcher's duty (grid <= occupancy x CUs, launch8k).
 // 16-byte store that is WRITTEN THROUGH this XCD's L2 (sc0 sc1): the image of the weight must be visible to the other seven
 // XCDs behind the barrier; written through, nothing of it is a dirty L2 line when the workgroups meet and the release side
 // of the barrier needs no `buffer_wbl2` sweep.  (tools/exp/nf4_time.py, M 17408 N 3840 K 2304 on a warm chip: the launch
@@ -115,8 +115,9 @@ __device__ __forceinline__ void store16_through(void* dst, u32x4 v) {
 __device__ __forceinline__ void nf4_fill_and_meet(const Lin8Params& p, unsigned char* lds) {
     const int tid = threadIdx.x;
     // (VFT_NF4_DEBUG & 16, tools/exp/nf4_time.py: cycle stamps of every workgroup at start / conversion done / barrier passed)
-    unsigned long long* stamps = (p.q_debug & 16) ? reinterpret_cast<unsigned long long*>(p.q_sync) + 32 + 4 * blockIdx.x : nullptr;
+    unsigned long long* stamps = (p.q_debug & 16) ? reinterpret_cast<unsigned long long*>(p.q_sync) + 512 + 4 * blockIdx.x : nullptr;  // byte 4096 on
     if (stamps && tid == 0) stamps[0] = wall_clock64();
+    const unsigned epoch = __hip_atomic_load(&p.q_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // launches so far (see the barrier)
     float* code_s = reinterpret_cast<float*>(lds + 64 * 260);
     if (tid < 16) code_s[tid] = p.q_code[tid];
     __syncthreads();
@@ -213,30 +214,37 @@ __device__ __forceinline__ void nf4_fill_and_meet(const Lin8Params& p, unsigned 
     //      sweeping the whole L2 for write-back and again for invalidation — cost ~50 us per launch in the first version).
     //      Acquire: ONE wave per workgroup drops the stale
     //      lines of the scratch (it is re-used by every NF4 layer) from this CU's L1 and this XCD's L2.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's image stores are acknowledged; `epoch` (below) has arrived
     __syncthreads();
     if (stamps && tid == 0) stamps[1] = wall_clock64();
     if (tid < 64) {
+        // Arrivals are counted in EIGHT words on their own cache lines (class = workgroup id & 7, i.e. the XCD: 32 atomics per
+        // word instead of 256 on one) that are never reset: every launch adds exactly 1024 to each word — the first workgroup
+        // of a class adds the difference to its class size, workgroup 0 also the 1024 of classes a small grid leaves empty —
+        // so the launch with epoch e is complete when every word has reached 1024 (e + 1) (compared modulo 2^32).  `epoch`
+        // was read before this workgroup arrived and is advanced by workgroup 0 once it is past the barrier, i.e. after
+        // every workgroup of this launch has read it.  No departure count, no reset, nothing returned by an atomic.
+        const unsigned grid = gridDim.x, cls = blockIdx.x & 7u;
         if (tid == 0) {
-            __hip_atomic_fetch_add(&p.q_sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            // bounded: every wave reaches the end of the kernel whatever happens (on a time-out the error word is set)
-            while (__hip_atomic_load(&p.q_sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) {
-                    __hip_atomic_store(&p.q_sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
+            unsigned add = 1u;
+            if (blockIdx.x == cls) add += 1024u - (grid - cls + 7u) / 8u;
+            __hip_atomic_fetch_add(&p.q_sync[64 + 16 * cls], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0)
+                for (unsigned c = grid; c < 8u; ++c) __hip_atomic_fetch_add(&p.q_sync[64 + 16 * c], 1024u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned target = (epoch + 1u) * 1024u;
+        unsigned spins = 0;
+        for (;;) {  // lanes 0..7 poll one word each; bounded: every wave reaches the end of the kernel whatever happens
+            const unsigned v = tid < 8 ? __hip_atomic_load(&p.q_sync[64 + 16 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {
+                if (tid == 0) __hip_atomic_store(&p.q_sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
             }
         }
         asm volatile("buffer_inv sc1" ::: "memory");
-        if (tid == 0) {
-            const unsigned left = __hip_atomic_fetch_add(&p.q_sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left == gridDim.x - 1) {  // everybody is past the spin: zero the counters for the next launch
-                __hip_atomic_store(&p.q_sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&p.q_sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        if (tid == 0 && blockIdx.x == 0) __hip_atomic_store(&p.q_sync[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
