@@ -659,6 +659,167 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnParams p) {
     }
 }
 
+// =============================================================================================
+// forward, head_dim 64 / 96, round 4: the 4-wave tiling of attn_fwd_kernel (128 queries per workgroup, 32 per wave, every
+// wave against all 64 keys of a tile, S^T = K Q^T with the softmax row on the lane, P from the accumulators straight into
+// O^T = V^T P^T) on the operand path of the newer kernels: K / V tiles arrive by asm LDS-DMA into the unpadded swizzled
+// image (head_dim 96: rows padded to 256 bytes, pad chunks requested out of range), double-buffered, one barrier per tile.
+// The round-1 kernel staged K / V through registers: its loop carried ~100 vector instructions of load addressing, range
+// checks and LDS stores per 64-key tile beside the ~160 of the softmax (ISA count, round 4) — on a kernel that is bound by
+// vector issue (16 MFMAs = 512 cycles against ~1 450 of VALU per tile and wave), and its padded image cost 24 % of the LDS
+// cycles in bank conflicts on the transposed V reads.  Lazy rescale of O as in attn_fwd2_kernel.
+// =============================================================================================
+template <int D, int ROWS, int NW>
+struct DmaTilePad;
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnParams p) {
+    constexpr int KS = D / 16, DT = D / 32, RB = D == 96 ? 256 : D * 2, TILE = 64 * RB;  // bytes of one K (or V) tile
+    typedef typename std::conditional<D == 96, DmaTilePad<D, 64, 4>, DmaTile<(D == 96 ? 128 : D), 64, 4>>::type Stage;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int qtile, bh;
+    if (!xcd_map((p.Sq + 127) / 128, p.B * p.Hq, qtile, bh)) return;  // block-uniform
+    const int b = bh / p.Hq, hq = bh % p.Hq, q0 = qtile * 128;
+    const int hkv = hq / (p.Hq / p.Hkv);
+    int kvl = p.Sk;
+    if (p.kv_len) kvl = min(max(p.kv_len[b], 0), p.Sk);
+
+    const bf16_t* Qb = p.q + b * p.sq.b + hq * p.sq.h;
+    const bf16_t* Kb = p.k + b * p.sk.b + hkv * p.sk.h;
+    const bf16_t* Vb = p.v + b * p.sv.b + hkv * p.sv.h;
+    bf16_t* Ob = p.o + b * p.so.b + hq * p.so.h;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((int64_t)(p.Sk - 1) * p.sk.s + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((int64_t)(p.Sk - 1) * p.sv.s + D) * 2), 0x00020000);
+
+    const int qrow = q0 + w * 32 + r;
+    const bool qok = qrow < p.Sq;
+    bf16x8 Qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Qf[ks] = ldg_frag(Qb + (int64_t)qrow * p.sq.s + ks * 16 + 8 * h, qok);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) pin_loaded(Qf[ks]);
+
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[dt][i] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+    const float sc = p.scale * kLog2e;
+
+    const int ntiles = (kvl + 63) / 64;
+    const int ks_s = (int)p.sk.s, vs_s = (int)p.sv.s;
+    if (ntiles > 0) {
+        Stage::issue(rk, smem, 0, kvl, ks_s);
+        Stage::issue(rv, smem + TILE, 0, kvl, vs_s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses of this lane (bytes inside a tile): K rows r (+32 kt), chunk 2 ks + h; V transposed: rows
+    // 16 kk + 4 h + (i >> 2) (+8), chunk 4 dt + 2 ((lane >> 4) & 1) + ((i & 3) >> 1) — the image of the other kernels
+    const int rbase = r * RB + ((h ^ swz_f<RB>(r)) << 4);
+    const int i16 = lane & 15, cc = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    int tbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int vr = 4 * h + (i16 >> 2) + 8 * hi;
+        tbase[hi] = vr * RB + ((cc ^ swz_f<RB>(vr)) << 4) + (i16 & 1) * 8;
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const char* Kc = smem + (t & 1) * 2 * TILE;
+        const char* Vc = Kc + TILE;
+        if (t + 1 < ntiles) {  // the other buffer was last read before the barrier that ended tile t-1
+            char* Kn = smem + ((t + 1) & 1) * 2 * TILE;
+            Stage::issue(rk, Kn, (t + 1) * 64, kvl, ks_s);
+            Stage::issue(rv, Kn + TILE, (t + 1) * 64, kvl, vs_s);
+        }
+        // S^T[key][q] = K Q^T (rows r + 32 kt of the tile: 32 kt RB is a multiple of the swizzle period)
+        f32x16 S[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[kt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kc + kt * 32 * RB + ((rbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256));
+                S[kt] = mfma32(a, Qf[ks], S[kt]);
+            }
+        }
+        const int n0 = t * 64;
+        if (n0 + 64 > kvl) {  // block-uniform: only the last key tile can be ragged
+            asm volatile("; ragged tail tile" ::: "memory");
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = n0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= kvl) S[kt][i] = -INFINITY;
+                }
+        }
+        float tmax = S[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, S[kt][i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        // lazy rescale (see attn_fwd2_kernel): m follows the running maximum only when it has grown by more than 2^8
+        const float ts = tmax * sc;
+        const float m_new = ts > m + 8.f ? ts : m;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(S[kt][i] * sc - m_new);
+                psum += pv;
+                S[kt][i] = pv;
+            }
+        lsum = lsum * alpha + psum;
+        m = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // exact skip once the running maxima have settled
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[dt][i] *= alpha;
+        }
+        bf16x8 Pf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) Pf[kk] = pack8(S[kk >> 1], kk & 1);
+        // O^T[d][q] += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const char* a0 = Vc + kk * 16 * RB + (dt >> 2) * 256;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (tbase[0] ^ ((dt & 3) << 6))));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + (tbase[1] ^ ((dt & 3) << 6))));
+                s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                O[dt] = mfma32(__builtin_bit_cast(bf16x8, both), Pf[kk], O[dt]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (issued a whole tile of compute ago)
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (qok) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t* dst = Ob + (int64_t)qrow * p.so.s + dt * 32 + 8 * g + 4 * h;
+                store4(dst, O[dt][4 * g] * inv, O[dt][4 * g + 1] * inv, O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+            }
+        if (h == 0 && p.lse) {
+            p.lse[((int64_t)b * p.Hq + hq) * p.Sq + qrow] = ltot > 0.f ? (m + __log2f(ltot)) * kLn2 : -INFINITY;
+        }
+    }
+}
+
 // Staggered form of attn_fwd2_kernel (same tiling, LDS image and pair merge): measured on MI355X it is 14-15 % faster at
 // head_dim 128 (574 -> 655-663 TF/s, B16 H16 S2048) and 13 % SLOWER at head_dim 256, where the second copy of the loop body
 // costs 24 spilled registers (728 -> 617 TF/s) — so it serves head_dim 128 only.
@@ -2799,6 +2960,20 @@ int launch_fwd(const AttnParams& p, hipStream_t st) {
 }
 
 template <int D>
+int launch_fwd3(const AttnParams& p, hipStream_t st) {  // head_dim 64 / 96: LDS-DMA operand path (round 4)
+    constexpr size_t lds = 2 * 2 * 64 * (D == 96 ? 256 : D * 2);  // double-buffered K + V tiles, head_dim 96 rows padded to 256 B
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid(xcd_grid((p.Sq + 127) / 128, p.B * p.Hq));
+    hipLaunchKernelGGL(attn_fwd3_kernel<D>, grid, dim3(256), lds, st, p);
+    VFT_CHECK_LAUNCH("vft_attn_fwd");
+    return 0;
+}
+
+template <int D>
 int launch_fwd2(const AttnParams& p, hipStream_t st) {
     // two K/V buffers (they also carry the pair merge: 8 x D/4 float4 x 64 lanes = the same bytes) + the pair's m / l
     constexpr size_t lds = 2 * 2 * 64 * D * sizeof(bf16_t) + 8 * 64 * sizeof(float2);
@@ -2966,8 +3141,8 @@ extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* o
     p.sq = mk(q_strides), p.sk = mk(k_strides), p.sv = mk(v_strides), p.so = mk(o_strides);
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
-        case 64: return launch_fwd<64>(p, st);
-        case 96: return launch_fwd<96>(p, st);
+        case 64: return g_attn_variant == 1 ? launch_fwd<64>(p, st) : launch_fwd3<64>(p, st);
+        case 96: return g_attn_variant == 1 ? launch_fwd<96>(p, st) : launch_fwd3<96>(p, st);
         case 128: return g_attn_variant == 1 ? launch_fwd<128>(p, st) : launch_fwd2<128>(p, st);
         default: return g_attn_variant == 1 ? launch_fwd<256>(p, st) : launch_fwd2<256>(p, st);
     }
