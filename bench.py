@@ -204,10 +204,10 @@ FAMILIES = {
     "attention_bwd": (("attn_bwd",), "attn_bwd1_kernel (one pass: head_dim 64 self-attention) / attn_bwd_dkdv3_kernel<.., true> + batched wg8_kernel (stored dS: "
                                      "head_dim >= 128) / attn_bwd_dq3_kernel + attn_bwd_dkdv3_kernel (short key sequences) / attn_bwd_dq_kernel + "
                                      "attn_bwd_dkdv4_kernel (head_dim 96)", "mfma"),
-    "attention_fwd": (("attn_fwd",), "attn_fwd_kernel (head_dim 64 / 96) / attn_fwd2_kernel (head_dim >= 128)", "mfma"),
+    "attention_fwd": (("attn_fwd",), "attn_fwd3_kernel (head_dim 64 / 96) / attn_fwd2_kernel (head_dim >= 128)", "mfma"),
     "conv3x3": (("conv3x3_fwd", "conv3x3_dgrad"), "lin8_kernel, implicit-GEMM mode (vft_conv3x3_fwd: forward and data gradient)", "mfma"),
     "weight_grad": (("linear_wgrad", "conv3x3_wgrad"), "wg8_kernel (vft_linear_wgrad / vft_conv3x3_wgrad: weight gradients of trainable projections and 3x3 convolutions)", "mfma"),
-    "gemm_nf4": (("gemm_nf4",), "NF4 dequantising projection GEMM (vft_linear_nf4)", "mfma"),
+    "gemm_nf4": (("gemm_nf4",), "lin8_kernel<.., NF4> (vft_linear_nf4: the launch dequantises the 4-bit weight once, then the bf16 main loop)", "mfma"),
     # NOT ours: the library GEMMs that remain (full fine-tune: trainable projections), timed like the rest so that the
     # dominant kernel is named honestly when it is theirs
     "library_gemm": (("lib_gemm",), "hipBLASLt Cijk_* (torch F.linear / matmul of trainable weights: forward, data gradient, large weight gradients)", "mfma"),
@@ -277,10 +277,10 @@ def pmc_traffic(family: str):
     gfx950 x2 fetch correction applied) — measured at the shape named in the note, not inside this run."""
     import csv
 
-    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd1_kernel",
+    want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd3_kernel", "attention_bwd": "attn_bwd1_kernel", "gemm_nf4": "lin8_nf4",
             "weight_grad": "wg8_kernel<false>"}.get(family)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r03_d_pmc_hbm_traffic.csv", "r03_c_pmc_hbm_traffic.csv", "r03_b_pmc_hbm_traffic.csv", "r03_a_pmc_hbm_traffic.csv", "r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r04_b_pmc_hbm_traffic.csv", "r04_a_pmc_hbm_traffic.csv", "r03_d_pmc_hbm_traffic.csv", "r03_c_pmc_hbm_traffic.csv", "r03_b_pmc_hbm_traffic.csv", "r03_a_pmc_hbm_traffic.csv", "r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         try:
             for row in csv.DictReader(open(os.path.join(root, name))):
                 if want and row["kernel"] == want:

@@ -76,3 +76,21 @@ for _ in range(3):
 torch.cuda.synchronize()
 print("wg8 linear algorithmic bytes (dy + x + dW) =", 2 * (Mw * Rw + Mw * Cw + Rw * Cw),
       " wg8 conv (dy + x + dW) =", 2 * (2 * Bq * Hq * Hq * Cq + 9 * Cq * Cq))
+
+# the NF4 projection GEMM of Lumina2-QLoRA (round 4: the launch dequantises the weight once, then the bf16 main loop): qkv
+# projection 2304 -> 3840 over B = 4 x 4352 tokens, rank-4 extension
+from vision_ft_amd.modules.quant import NF4Linear, quantize_nf4  # noqa: E402
+
+Mn, out_f, in_f = 17408, 3840, 2304
+qn = quantize_nf4(torch.randn(out_f, in_f) * in_f**-0.5, double_quant=True)
+layer = NF4Linear(in_f, out_f, bias=False)
+layer.load_state_dict({"weight" + k_: v_ for k_, v_ in qn.items()}, strict=True)
+layer = layer.to(dev)
+xn, tn, Bn = bf(Mn, in_f), bf(Mn, 4), bf(out_f, 4)
+_C.check(_C.lib().vft_linear_variant(1), "vft_linear_variant")
+for _ in range(3):
+    kernels._nf4_gemm(xn, layer.quant_state(), None, False, ext_x=tn, ext_w=Bn)
+_C.check(_C.lib().vft_linear_variant(0), "vft_linear_variant")
+torch.cuda.synchronize()
+print("lin8 NF4 algorithmic bytes (x + y + codes + absmax; the bf16 image written once and read by the main loop comes on top) =",
+      2 * Mn * (in_f + out_f) + out_f * in_f // 2 + out_f * in_f // 16)

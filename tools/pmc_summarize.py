@@ -9,6 +9,7 @@ import sys
 
 ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
     "attn_fwd_kernel": 4 * 24 * 10 * 4096 * 64 * 2 / 1e6,
+    "attn_fwd3_kernel": 4 * 24 * 10 * 4096 * 64 * 2 / 1e6,  # round 4: head_dim 64 / 96 forward on the LDS-DMA operand path
     "attn_bwd_dq_kernel": 5 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "attn_bwd_dkdv_kernel": 6 * 24 * 10 * 4096 * 64 * 2 / 1e6,
     "attn_bwd_dq3_kernel": 5 * 24 * 10 * 4096 * 64 * 2 / 1e6,
@@ -34,7 +35,10 @@ ALG_MB = {  # algorithmic HBM bytes per launch of the shapes in tools/pmc_run.py
 }
 LIN8_SHAPES = [("lin8_kernel", "M=98304 N=5120 K=640 (+bias + rank-4 extension)", 2 * (98304 * 640 + 5120 * 640 + 98304 * 5120 + 4 * (98304 + 5120)) / 1e6),
                ("lin8_kernel_b", "M=24576 N=10240 K=1280 (+bias + rank-4 extension)", 2 * (24576 * 1280 + 10240 * 1280 + 24576 * 10240 + 4 * (24576 + 10240)) / 1e6),
-               ("lin8_conv", "conv3x3 320->320 @128x128 B=24", (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6)]
+               ("lin8_conv", "conv3x3 320->320 @128x128 B=24", (2 * 24 * 128 * 128 * 640 + 18 * 320 * 320) / 1e6),
+               # round 4: NF4 weight dequantised once inside the launch (x + y + packed codes + absmax; the bf16 image — written
+               # once, read once per XCD through L2 — is what the measured traffic shows on top)
+               ("lin8_nf4", "NF4 M=17408 N=3840 K=2304 (+ rank-4 extension)", (2 * 17408 * (2304 + 3840) + 3840 * 2304 // 2 + 3840 * 2304 // 16) / 1e6)]
 
 
 def per_kernel(d, counter):
@@ -46,6 +50,11 @@ def per_kernel(d, counter):
             continue
         name = r["Kernel_Name"]
         if "lin8_kernel" in name:  # plain launches: 3 of the first shape, then 3 of the second; conv launches: Lb1 in the template
+            import re
+            if re.search(r"false>\s*>?, true>", name) or "ELb0EEELb1E" in name:  # C8<.., false>, NF4 = true
+                acc["lin8_nf4"] += float(r["Counter_Value"])
+                n["lin8_nf4"] += 1
+                continue
             conv = "ELb1EE" in name or ", true>" in name
             key = "lin8_conv" if conv else ("lin8_kernel" if lin8_seen < 3 else "lin8_kernel_b")
             lin8_seen += 0 if conv else 1

@@ -43,6 +43,9 @@ def main():
         if "wg8_" in n:
             return "weight grad(ours, wg8)"
         if "lin8_kernel" in n:
+            import re
+            if re.search(r"false>\s*>?, true>", n) or "ELb0EEELb1E" in n:  # C8<.., CONV = false>, NF4 = true (round 4)
+                return "NF4 gemm(ours, lin8: dequantised once per launch)"
             return "conv3x3(ours, lin8)" if "ELb1EE" in n or ", true>" in n else "linear gemm(ours, lin8)"
         if "linear_kernel" in n:
             return "conv3x3/linear(ours, gen 1)"
