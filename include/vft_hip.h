@@ -104,7 +104,7 @@ int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora
 int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
                   float scale, void* stream);
 int vft_lora_wgrad_target(int workgroups); /* tuning / A-B: workgroups the weight-gradient row blocking aims at; 0 = automatic */
-int vft_lora_down_variant(int variant); /* tuning / A-B: 0 = automatic (32 token rows per workgroup, 64 for rank > 8 at M >= 65536), 1 = 16, 2 = 64, 3 = 32 */
+int vft_lora_down_variant(int variant); /* tuning / A-B: 0 = automatic (32 token rows per workgroup, 64 for rank > 8 at M >= 16384), 1 = 16, 2 = 64, 3 = 32 */
 int vft_lora_bwd_dx(const void* dy, void* dx, const void* lora_up_t, const void* lora_down, void* u_out,
                     int M, int N, int K, int r, int64_t lddy, int64_t lddx, float scale, void* stream);
 size_t vft_lora_wgrad_workspace(int M, int K, int N, int r);

@@ -535,7 +535,7 @@ extern "C" int vft_lora_fwd(const void* x, void* y, const void* lora_down, const
 
 // t[M][r] = x[M][K] . lora_down[r][K]^T only (the low-rank activations; the update itself is applied by the consumer:
 // vft_geglu_lora_*, or the rank extension of vft_linear_fwd / vft_linear_nf4)
-// A/B control (vft_lora_down_variant): 0 = automatic (32 rows per workgroup; 64 at rank > 8 and M >= 65536), 1 = the 16-row
+// A/B control (vft_lora_down_variant): 0 = automatic (32 rows per workgroup; 64 at rank > 8 and M >= 16384), 1 = the 16-row
 // phase 1 of lora_rows_kernel, 2 = 64 rows, 3 = 32 rows
 static int g_lora_down_variant = 0;
 extern "C" int vft_lora_down_variant(int v) {
@@ -550,7 +550,12 @@ extern "C" int vft_lora_down(const void* x, const void* lora_down, void* t_out, 
     VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)lora_down) & 15) == 0, "vft_lora_down: operands must be 16-byte aligned");
     if (g_lora_down_variant == 1)
         launch_rows<true>(x, nullptr, lora_down, nullptr, t_out, nullptr, nullptr, 0, M, K, 0, r, ldx, 0, scale, (hipStream_t)stream);
-    else if (g_lora_down_variant == 2 || (g_lora_down_variant == 0 && r > 8 && M >= 65536))  // measured: 64 rows pay only there
+    // 64 rows per workgroup at rank > 8.  Round 2 measured them on inputs that sat in the Infinity Cache and found them better
+    // only from M = 65 536 on; on COLD inputs — the in-step case, tools/exp/lora_down_cold.py cycles through 700 MB of them —
+    // they are 10-20 % faster at AuraFlow's M = 26 160 too (K 3072: 48.7 -> 44.1 us, K 8192: 134 -> 112), and 25-45 % SLOWER
+    // at rank 4 whatever M.  Tried in round 4 and dropped: a contiguous quarter of K per wave instead of interleaved k-steps
+    // (10-20 % slower: four waves of a workgroup walking one row together keep the DRAM pages open)
+    else if (g_lora_down_variant == 2 || (g_lora_down_variant == 0 && r > 8 && M >= 16384))
         hipLaunchKernelGGL(lora_down32_kernel<4>, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                            (const bf16_t*)lora_down, (bf16_t*)t_out, M, K, r, ldx, scale);
     else
