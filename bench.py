@@ -362,6 +362,10 @@ def main():
     from vision_ft_amd.trainer.dp import DataParallelGrads
 
     gemm_table = False if args.no_gemm_table else tuning.enable(tune=args.tune_gemms and rank == 0)
+    if os.environ.get("VFT_LORA_WGRAD_TARGET"):  # A/B knob: workgroups the LoRA weight-gradient row blocking aims at (0 = automatic)
+        from vision_ft_amd import _C as _c
+
+        _c.lib().vft_lora_wgrad_target(int(os.environ["VFT_LORA_WGRAD_TARGET"]))
     default_batch = {"sdxl_lora": 24, "sdxl_full": 24, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4, "sdxl_buckets": 16}
 
     def fence():

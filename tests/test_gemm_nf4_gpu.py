@@ -188,7 +188,7 @@ def test_nf4_dequant_once_equals_the_bf16_gemm_on_the_dequantised_weight_bitwise
                 assert torch.equal(dx, kernels.linear_fused(dy, w.t().contiguous())), (rep, w.shape, M)
     torch.cuda.synchronize()
     assert not kernels.nf4_barrier_timed_out()
-    hdr = kernels._NF4_WS[torch.device(gpu)][-1][:1024].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    hdr = kernels._nf4_workspace(torch.device(gpu), 1)[:1024].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     launches = int(hdr[0])  # the launch counter; every arrival word stands at 1024 per launch, whatever the grids were
     assert launches >= 2 * 4 * 2 * 2 and all(int(hdr[64 + 16 * c]) == (1024 * launches) % 2**32 for c in range(8)), hdr[:200:16]
 

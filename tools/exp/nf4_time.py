@@ -57,7 +57,7 @@ for out_f, in_f in [(3840, 2304), (2304, 2304), (6144, 2304), (2304, 6144)]:
     res["once fwd (again)"] = timeit(lambda: kernels._nf4_gemm(x, qs, None, False))
     res["once dgrad (again)"] = timeit(lambda: kernels._nf4_gemm(dy, qs, None, True))
     os.environ["VFT_NF4_DEBUG"] = "16"
-    ws = kernels._NF4_WS[dev][-1]
+    ws = kernels._nf4_workspace(dev, 1)
     for _ in range(3):
         kernels._nf4_gemm(x, qs, None, False)
     torch.cuda.synchronize()

@@ -2080,7 +2080,10 @@ _NF4_WS: dict = {}  # device -> list of workspaces ever handed out (never freed:
 
 def _nf4_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     """One scratch per device, shared by every NF4 layer (launches on a stream are ordered, and a launch is done with the
-    scratch when it ends).  Its first 16 KiB hold the grid barrier's words (launch counter, arrival words, error flag): zero at first use.  Grows by allocating a NEW buffer (the old one stays alive for graphs captured with it)."""
+    scratch when it ends).  NOT for two streams at once: the trainers launch the step on one stream; keyed by device and not
+    by stream on purpose — the eager warm-up (side stream) creates and zeroes it, so that the capture that follows finds it
+    and records no 32 MB fill into the graph.  Its first 16 KiB hold the grid barrier's words (launch counter, arrival words,
+    error flag): zero at first use.  Grows by allocating a NEW buffer (the old one stays alive for graphs captured with it)."""
     pool = _NF4_WS.setdefault(device, [])
     if not pool or pool[-1].numel() < nbytes:
         pool.append(torch.zeros(max(nbytes, 32 << 20), dtype=torch.uint8, device=device))
