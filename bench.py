@@ -124,7 +124,6 @@ def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int
     else:
         lat, cap = rn(batch, 16, 128, 128), rn(batch, 256, 2304)
         full = torch.ones(batch, 256, dtype=torch.bool, device=device)
-        draw = torch.Generator().manual_seed(1000 + seed)  # host side: a data loader knows the lengths before the copy
         pos = torch.arange(256, device=device)[None, :]
 
         def fwd():
@@ -132,13 +131,17 @@ def make_step(workload: str, model, device, batch: int, seed: int, wh: tuple[int
             noisy, noise = LF.prepare_noised_latents(lat, (1 - t).to(lat.dtype))
             # caption lengths as host integers (a data loader knows them before the batch goes to the device): without them the
             # model reads them back from the mask — the step's only host synchronisation, which also rules out graph replay
-            if drawn_lengths:  # mask lengths U{32..256}, seeded; a new ragged layout every step
-                lens = torch.randint(32, 257, (batch,), generator=draw).tolist()
-                mask = pos < torch.tensor(lens, device=device)[:, None]
+            if drawn_lengths:
+                # mask lengths U{32..256}, a new ragged layout every step.  Round 4: drawn ON THE DEVICE
+                # (graph-safe Philox stream of the default generator) and fed to the shape-static forward — the lengths never
+                # reach the host, one HIP graph serves every combination (rounds 2-3: drawn on the host, eager launches)
+                lens_d = torch.randint(32, 257, (batch,), device=device)
+                mask = pos < lens_d[:, None]
+                out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask, static_layout=True)
             else:
                 lens, mask = [256] * batch, full
-            out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask, caption_lengths=lens,
-                              padded_output=True)
+                out, _, _ = model(latents=noisy, timestep=t, caption_features=cap, caption_mask=mask, caption_lengths=lens,
+                                  padded_output=True)
             pred = -out
             return LF.loss_with_predicted_velocity(lat.float(), noise.float(), pred.float())
     return fwd
@@ -386,7 +389,7 @@ def main():
         model = build(workload, device, use_rope=use_rope, aura_keys=aura_keys)
         params = [p for p in model.parameters() if p.requires_grad]
         dp = DataParallelGrads(params)
-        use_graph = not args.no_graph and not drawn_lengths
+        use_graph = not args.no_graph
         # (full fine-tune: 1e-3 — the reference's default AdamW rate, src/config.py:22-26, meant for adapters — on 2.6 B randomly
         #  initialised weights diverges within three steps and the line would report loss = nan; throughput does not depend on it)
         lr = 1e-5 if workload == "sdxl_full" else 1e-3
@@ -533,7 +536,7 @@ def main():
                                "module state / checkpoint format; compute on a dequantised bf16 cache (VFT_NF4_CACHE=1: NOT the "
                                "config as BASELINE states it — a labelled memory-for-speed option)"
                                if _nf4_cache_on() else "the only copy in HBM, dequantised inside the GEMM kernel (VFT_NF4_CACHE=0, default)"),
-                               "caption_lengths": "U{32..256} drawn per step (seeded), eager launches" if drawn_lengths else "256 (fixed)"}
+                               "caption_lengths": "U{32..256} drawn per step on the device, shape-static forward" if drawn_lengths else "256 (fixed)"}
                               if workload.startswith("lumina") else {}),
                            **({"use_rope": use_rope, "lora_key_set": "configs/auraflow/lora.yml (124 Linears)" if aura_keys == "yaml124"
                                else "tests/assets/debug_dataset.yml (252 Linears)"} if workload.startswith("aura") else {})},

@@ -427,3 +427,77 @@ def test_sdxl_full_finetune_gradients_through_the_weight_gradient_kernels(gpu):
     for n, p in model.named_parameters():
         e = rel_err(p.grad.float().cpu(), 2 * first[n].float().cpu())
         assert e < 2e-2, (n, e)
+
+
+def test_lumina2_static_layout_equals_the_ragged_forward(gpu):
+    """Round 4: `static_layout=True` (caption lengths stay on the device, every shape independent of them) computes what the
+    ragged forward computes — the reference's outputs of the golden fixture, the same input gradient and parameter gradients —
+    and ONE captured graph serves different caption-length combinations (the mask is the only thing that changes)."""
+    from vision_ft_amd.models.lumina2 import Denoiser, DenoiserConfig
+    from vision_ft_amd.modules.loss.flow_match import loss_with_predicted_velocity
+
+    T, meta = load_golden("lumina_tiny.safetensors")
+    cfgd = json.loads(meta["config"])
+    with torch.device("meta"):
+        shape_mod = Denoiser(DenoiserConfig(**cfgd))
+    Pb = {k: v.to(torch.bfloat16).float() for k, v in synth_params(shape_mod, 2, meta["checksum"]).items()}
+    model = _to_gpu_module(Denoiser, DenoiserConfig(**cfgd), Pb, gpu)
+    model.train()
+    g = {k: T[k].to(gpu) for k in ("timestep", "caption", "caption_mask", "noise", "latents")}
+    assert len(set(g["caption_mask"].sum(-1).tolist())) > 1  # the fixture's captions have different lengths
+
+    def run(static: bool, mask):
+        x = T["noisy"].to(gpu).clone().requires_grad_(True)
+        model.zero_grad(set_to_none=True)
+        if static:
+            o, _, capf = model(latents=x, timestep=g["timestep"], caption_features=g["caption"], caption_mask=mask, static_layout=True)
+        else:
+            o, _, capf = model(latents=x, timestep=g["timestep"], caption_features=g["caption"], caption_mask=mask,
+                               caption_lengths=mask.sum(-1).tolist(), padded_output=True)
+        loss = loss_with_predicted_velocity(g["latents"], g["noise"], (-o).float())
+        loss.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return o.detach(), float(loss), x.grad.detach().clone(), grads, capf.detach()
+
+    o_r, l_r, gx_r, gp_r, cap_r = run(False, g["caption_mask"])
+    o_s, l_s, gx_s, gp_s, cap_s = run(True, g["caption_mask"])
+    assert rel_err((-o_s).cpu(), T["out"]) < TENSOR_TOL  # the reference's own output
+    assert rel_err(o_s.float().cpu(), o_r.float().cpu()) < 4e-3, rel_err(o_s.float().cpu(), o_r.float().cpu())
+    assert abs(l_s - l_r) < 1e-3 * abs(l_r)
+    assert rel_err(gx_s.float().cpu(), gx_r.float().cpu()) < 1e-2
+    assert set(gp_s) == set(gp_r)
+    worst = max(rel_err(gp_s[n].cpu(), gp_r[n].cpu()) for n in gp_r if gp_r[n].abs().max() > 0)
+    assert worst < 3e-2, worst
+    for i, n in enumerate(g["caption_mask"].sum(-1).tolist()):  # refined captions: the valid rows
+        assert rel_err(cap_s[i, :n].float().cpu(), cap_r[i, :n].float().cpu()) < 4e-3
+
+    # one graph, two different length combinations
+    model.requires_grad_(False)
+    xs = T["noisy"].to(gpu).clone()
+    mask_static = g["caption_mask"].clone()
+
+    def fwd():
+        o, _, _ = model(latents=xs, timestep=g["timestep"], caption_features=g["caption"], caption_mask=mask_static, static_layout=True)
+        return o
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        out_static = fwd()
+    L = mask_static.shape[1]
+    for lens in (g["caption_mask"].sum(-1).tolist(), [L] * mask_static.shape[0], [max(1, L // 3), L][: mask_static.shape[0]] + [2] * max(0, mask_static.shape[0] - 2)):
+        lens = lens[: mask_static.shape[0]]
+        m = torch.arange(L, device=gpu)[None, :] < torch.tensor(lens, device=gpu)[:, None]
+        mask_static.copy_(m)
+        graph.replay()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            want, _, _ = model(latents=xs, timestep=g["timestep"], caption_features=g["caption"], caption_mask=m,
+                               caption_lengths=lens, padded_output=True)
+        assert rel_err(out_static.float().cpu(), want.float().cpu()) < 4e-3, lens
+    model.requires_grad_(True)

@@ -35,7 +35,14 @@ class Lumina2ForTextToImageTraining(DenoiserTask):
     model_config_class = Lumina2ForTextToImageTrainingConfig
     latent_channels = 16
     pipeline_class = Lumina2
-    graph_safe = False  # the ragged batch assembly reads caption lengths on the host once per step
+    # Round 4: the step runs the shape-static forward (`NextDiT._forward_static`): caption lengths never leave the device, every
+    # batch of a bucket has the same tensor shapes, so the trainer replays it from one HIP graph per bucket like the other two
+    # families (rounds 1-3: eager, one host read of the lengths per step).  `static_layout = False` restores that path.
+    static_layout = True
+
+    @property
+    def graph_safe(self) -> bool:  # (the `shift_fraction_uniform` sampler draws on the host with numpy: not capturable)
+        return self.static_layout and self.model_config.timestep_sampling != "shift_fraction_uniform"
 
 
     def make_conditions(self, batch, width, height, seed):
@@ -64,9 +71,13 @@ class Lumina2ForTextToImageTraining(DenoiserTask):
         # reference forward_and_loss :100-142: Lumina2 time runs 0 (noise) -> 1 (clean); prediction sign flipped
         t = self.sample_timesteps(latents.shape)
         noisy, noise = prepare_noised_latents(latents, (1 - t).to(latents.dtype))
-        out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"],
-                               caption_lengths=cond.get("caption_lengths"),  # host integers when the producer has them
-                               padded_output=True)  # = to_padded_tensor(nested output, 0.0), capturable
+        if self.static_layout and cond.get("caption_lengths") is None and noisy.dim() == 4:
+            out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"],
+                                   static_layout=True)
+        else:
+            out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"],
+                                   caption_lengths=cond.get("caption_lengths"),  # host integers when the producer has them
+                                   padded_output=True)  # = to_padded_tensor(nested output, 0.0), capturable
         pred = -out
         loss = loss_with_predicted_velocity(latents, noise, pred)
         if self.model_config.use_downsampled_velocity_loss:

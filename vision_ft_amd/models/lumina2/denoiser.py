@@ -235,6 +235,31 @@ def _pad_rows(items: list[torch.Tensor], device, want_mask: bool = True) -> tupl
     return padded, mask, lens
 
 
+class _TakeRows(torch.autograd.Function):
+    """out[j] = src[idx[j]] (idx[j] < 0: a zero row) for an index that hits every source row AT MOST ONCE — the row moves of
+    the static-shape batch assembly below.  Backward is the inverse gather (no scatter-add, no atomics: deterministic), built
+    from the index on the device with static shapes, so both directions replay from a HIP graph."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        valid = idx >= 0
+        out = torch.where(valid.unsqueeze(-1), src.index_select(0, idx.clamp_min(0)), src.new_zeros(()))
+        ctx.save_for_backward(idx, valid)
+        ctx.rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, valid = ctx.saved_tensors
+        n = ctx.rows
+        inv = torch.full((n + 1,), -1, dtype=torch.long, device=idx.device)
+        # invalid entries all land in the spare slot n
+        inv.scatter_(0, torch.where(valid, idx, torch.full_like(idx, n)), torch.arange(idx.numel(), device=idx.device))
+        inv = inv[:n]
+        gs = torch.where((inv >= 0).unsqueeze(-1), g.index_select(0, inv.clamp_min(0)), g.new_zeros(()))
+        return gs, None
+
+
 class NextDiT(nn.Module):
     def __init__(self, patch_size: int = 2, in_channels: int = 16, hidden_dim: int = 2304, timestep_embed_dim: int = 256,
                  num_layers: int = 24, num_refiner_layers: int = 2, num_heads: int = 24, num_kv_heads: int = 8,
@@ -358,12 +383,75 @@ class NextDiT(nn.Module):
         cache[key] = hit
         return hit
 
+    def _forward_static(self, latents: torch.Tensor, caption_features: torch.Tensor, timestep: torch.Tensor,
+                        caption_mask: torch.Tensor):
+        """The same forward pass with EVERY shape independent of the caption lengths (round 4): one same-size image batch
+        (B,C,H,W), captions padded to L rows with a prefix mask.  The lengths stay on the device (`caption_mask.sum`): position
+        ids -> rotary tables, the [caption | image] assembly and the final split are gathers by indices computed from them,
+        the sequences are L + N rows long for every sample (rows behind a sample's end are dead: masked as keys through
+        `kv_len`, ignored as queries), so ONE captured HIP graph serves every batch of a bucket — the reference's per-sample
+        Python assembly (src/models/lumina2/denoiser.py:809-932) reads the lengths on the host four times per sample.
+        Valid rows see exactly the operations of `forward` (same kernels, same key ranges)."""
+        dev = timestep.device
+        dtype = module_dtype(self.x_embedder)
+        b, c, H, W = latents.shape
+        p = self.patch_size
+        gh, gw = H // p, W // p
+        N, L = gh * gw, caption_features.shape[1]
+        T = L + N
+        with torch.no_grad():
+            ck = caption_mask.bool().sum(dim=-1, dtype=torch.int32)  # (B,) valid caption rows — never leaves the device
+            tk = ck + N
+            ik = torch.full((b,), N, dtype=torch.int32, device=dev)
+            lenb = ck.long().unsqueeze(1)
+            s_ = torch.arange(T, device=dev).unsqueeze(0)
+            is_cap = s_ < lenb
+            j = (s_ - lenb).clamp(0, N - 1)
+            in_img = (~is_cap) & (s_ < lenb + N)
+            zero = torch.zeros((), dtype=torch.long, device=dev)
+            ids = torch.stack([torch.where(is_cap, s_, torch.where(in_img, lenb, zero)),
+                               torch.where(in_img, j // gw, zero), torch.where(in_img, j % gw, zero)], dim=-1)
+            rope = self.rope_embedder(ids)
+            cap_ids = torch.stack([torch.arange(L, device=dev), torch.zeros(L, dtype=torch.long, device=dev),
+                                   torch.zeros(L, dtype=torch.long, device=dev)], dim=-1).unsqueeze(0).expand(b, -1, -1)
+            cap_rope = self.rope_embedder(cap_ids)
+            jn = torch.arange(N, device=dev)
+            img_ids = torch.stack([lenb.expand(b, N), (jn // gw).unsqueeze(0).expand(b, N), (jn % gw).unsqueeze(0).expand(b, N)], dim=-1)
+            img_rope = self.rope_embedder(img_ids)
+            boff = (torch.arange(b, device=dev) * T).unsqueeze(1)  # source rows per sample: L caption rows, then N image rows
+            gidx = (torch.where(is_cap, s_, torch.where(in_img, L + j, torch.full_like(s_, -1))) + torch.where(is_cap | in_img, boff, zero)).reshape(-1)
+            oidx = (lenb + jn.unsqueeze(0) + boff).reshape(-1)
+
+        t = self.t_embedder(timestep)
+        cap = self.cap_embedder[1](kernels.rms_norm_scale(caption_features.to(dtype), self.cap_embedder[0].weight, None,
+                                                          self.cap_embedder[0].eps))
+        for layer in self.context_refiner:
+            cap = self._run(layer, cap, cap_rope, None, None, ck)
+        patches = latents.to(dtype).reshape(b, c, gh, p, gw, p).permute(0, 2, 4, 3, 5, 1).reshape(b, N, p * p * c)
+        x = self.x_embedder(patches)
+        for layer in self.noise_refiner:
+            x = self._run(layer, x, img_rope, t, None, ik)
+        ctx = _TakeRows.apply(torch.cat([cap, x], dim=1).reshape(b * T, -1), gidx).view(b, T, -1)
+        for layer in self.layers:
+            ctx = self._run(layer, ctx, rope, t, None, tk)
+        out = self.final_layer(ctx, t)
+        pieces = _TakeRows.apply(out.reshape(b * T, -1), oidx).view(b, gh, gw, p, p, self.out_channels)
+        images = pieces.permute(0, 5, 1, 3, 2, 4).reshape(b, self.out_channels, gh * p, gw * p)
+        return images, caption_mask.bool(), cap
+
     def forward(self, latents, caption_features, timestep: torch.Tensor, caption_mask, cached_caption_features=None,
-                caption_lengths: list[int] | None = None, padded_output: bool = False):
+                caption_lengths: list[int] | None = None, padded_output: bool = False, static_layout: bool = False):
         """`caption_lengths`: the number of valid caption tokens per sample as host integers, when the caller has them
         (the data loader knows them before the batch goes to the device); without them they are read back from
         `caption_mask` — the forward pass's only host synchronisation.  `padded_output`: return the images zero-padded to
-        the largest one and stacked (= `torch.nested.to_padded_tensor(out, 0.0)` of the default nested output)."""
+        the largest one and stacked (= `torch.nested.to_padded_tensor(out, 0.0)` of the default nested output).
+        `static_layout`: the shape-static form for one same-size batch (`_forward_static`): no host integers at all, one HIP
+        graph for every caption-length combination; returns the stacked images."""
+        if static_layout:
+            if not (isinstance(latents, torch.Tensor) and not latents.is_nested and latents.dim() == 4 and isinstance(caption_features, torch.Tensor)
+                    and caption_features.dim() == 3 and isinstance(caption_mask, torch.Tensor) and cached_caption_features is None):
+                raise ValueError("static_layout needs one same-size image batch (B,C,H,W), dense caption features (B,L,C) and a (B,L) prefix mask")
+            return self._forward_static(latents, caption_features, timestep, caption_mask)
         dev = timestep.device
         dtype = module_dtype(self.x_embedder)
         images = list(latents.unbind()) if isinstance(latents, torch.Tensor) else list(latents)
