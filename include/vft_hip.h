@@ -354,6 +354,10 @@ int vft_transpose_bf16(const void* src, void* dst, int R, int C, int64_t ld_src,
  * scratch: vft_mean_sq_scratch_floats() floats.  x 16-byte aligned. */
 int64_t vft_mean_sq_scratch_floats(void);
 int vft_mean_sq(const float* x, float* out, float* scratch, int64_t n, void* stream);
+/* out[0] (+)= sum(x[i]^2) over a dense bf16 buffer (accumulate != 0: added to out[0]): the squared L2 norm of a flat gradient
+ * buffer = the reduction of gradient-norm clipping (ModelForTraining.after_backward -> clip_grad_norm_,
+ * src/models/for_training.py:171-189).  Same scheme and scratch as vft_mean_sq. */
+int vft_sum_sq_bf16(const void* x, float* out, float* scratch, int64_t n, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -350,3 +350,22 @@ def test_mse_loss_reduction_kernel(gpu, shape, cl):
             torch.cuda.synchronize()
         graph.replay()
         assert float(out) == float(loss)
+
+
+def test_flat_gradient_clipping_matches_torch(gpu):
+    """kernels.clip_flat_grad_norm_ = torch.nn.utils.clip_grad_norm_ on gradients that are views into flat bf16 buffers (fp32 sum of
+    squares on vft_sum_sq_bf16 instead of a multi-tensor pass), for a norm above and below the threshold, two buffers."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(3)
+    for scale, max_norm in ((1.0, 1.0), (1e-4, 1.0)):
+        bufs = [(torch.randn(n, generator=g) * scale).to(torch.bfloat16).to(gpu) for n in (1_000_003 // 8 * 8, 4096)]
+        ref = [b.clone().float().requires_grad_(False) for b in bufs]
+        params = [torch.nn.Parameter(torch.zeros_like(r)) for r in ref]
+        for p_, r in zip(params, ref):
+            p_.grad = r.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+        got_norm = kernels.clip_flat_grad_norm_(bufs, max_norm)
+        assert abs(float(got_norm) - float(want_norm)) < 1e-4 * float(want_norm)
+        for b, p_ in zip(bufs, params):
+            assert rel_err(b.float().cpu(), p_.grad.cpu()) < 4e-3

@@ -78,6 +78,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
     "vft_mean_sq_scratch_floats": (c_int64, []),
     "vft_mean_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vft_sum_sq_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "vft_linear_nf4": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_int64] * 3 + [c_int, c_void_p, c_int64, c_void_p]),
     "vft_linear_nf4_workspace": (c_int64, [c_int, c_int]),
     "vft_conv3x3_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),

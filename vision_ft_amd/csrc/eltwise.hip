@@ -426,20 +426,27 @@ extern "C" int vft_transpose_bf16(const void* src, void* dst, int R, int C, int6
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int MSQ_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void mean_sq_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t n) {
+// T = float: 4 elements per 16-byte load; T = bf16_t: 8
+template <class T>
+__global__ __launch_bounds__(256) void mean_sq_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t n) {
+    constexpr int V = 16 / sizeof(T);
     __shared__ float red[256];
-    const int64_t chunk = ((n + MSQ_BLOCKS - 1) / MSQ_BLOCKS + 3) / 4 * 4;  // multiple of 4 floats: 16-byte loads stay aligned
+    const int64_t chunk = ((n + MSQ_BLOCKS - 1) / MSQ_BLOCKS + V - 1) / V * V;  // multiple of V elements: 16-byte loads stay aligned
     const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
     float s = 0.f;
-    for (int64_t i = b0 + 4 * (int64_t)threadIdx.x; i < b1; i += 1024) {
-        if (i + 4 <= b1) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
-            s += v[0] * v[0];
-            s += v[1] * v[1];
-            s += v[2] * v[2];
-            s += v[3] * v[3];
+    for (int64_t i = b0 + V * (int64_t)threadIdx.x; i < b1; i += 256 * V) {
+        if (i + V <= b1) {
+            if constexpr (sizeof(T) == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += v[j] * v[j];
+            } else {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)v[j] * (float)v[j];
+            }
         } else {
-            for (int64_t j = i; j < b1; ++j) s += x[j] * x[j];
+            for (int64_t j = i; j < b1; ++j) s += (float)x[j] * (float)x[j];
         }
     }
     red[threadIdx.x] = s;
@@ -450,7 +457,8 @@ __global__ __launch_bounds__(256) void mean_sq_partial_kernel(const float* __res
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-__global__ __launch_bounds__(256) void mean_sq_final_kernel(const float* __restrict__ partial, float* __restrict__ out, float inv_n) {
+// out[0] (+)= scale * sum of the partials (accumulate: several buffers folded into one sum, launch after launch)
+__global__ __launch_bounds__(256) void mean_sq_final_kernel(const float* __restrict__ partial, float* __restrict__ out, float scale, int accumulate) {
     __shared__ float red[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < MSQ_BLOCKS; i += 256) s += partial[i];
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256) void mean_sq_final_kernel(const float* __restr
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0] * inv_n;
+    if (threadIdx.x == 0) out[0] = red[0] * scale + (accumulate ? out[0] : 0.f);
 }
 }  // namespace
 
@@ -469,8 +477,21 @@ extern "C" int64_t vft_mean_sq_scratch_floats(void) { return MSQ_BLOCKS; }
 extern "C" int vft_mean_sq(const float* x, float* out, float* scratch, int64_t n, void* stream) {
     VFT_CHECK_ARG(x && out && scratch, "vft_mean_sq: null pointer");
     VFT_CHECK_ARG(n > 0 && ((uintptr_t)x & 15) == 0, "vft_mean_sq: needs n > 0 and a 16-byte aligned input (n=%lld)", (long long)n);
-    hipLaunchKernelGGL(mean_sq_partial_kernel, dim3(MSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, scratch, n);
-    hipLaunchKernelGGL(mean_sq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, out, (float)(1.0 / (double)n));
+    hipLaunchKernelGGL(mean_sq_partial_kernel<float>, dim3(MSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, scratch, n);
+    hipLaunchKernelGGL(mean_sq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, out, (float)(1.0 / (double)n), 0);
     VFT_CHECK_LAUNCH("vft_mean_sq");
+    return 0;
+}
+
+// out[0] (+)= sum(x[i]^2) over a dense bf16 buffer: the squared L2 norm of a flat gradient buffer, i.e. the reduction of
+// gradient-norm clipping (reference: ModelForTraining.after_backward -> clip_grad_norm_, src/models/for_training.py:171-189),
+// on the same two-launch scheme — for the same reason and because one pass over ONE buffer replaces a
+// multi-tensor pass over 1 400 gradient views.
+extern "C" int vft_sum_sq_bf16(const void* x, float* out, float* scratch, int64_t n, int accumulate, void* stream) {
+    VFT_CHECK_ARG(x && out && scratch, "vft_sum_sq_bf16: null pointer");
+    VFT_CHECK_ARG(n > 0 && ((uintptr_t)x & 15) == 0, "vft_sum_sq_bf16: needs n > 0 and a 16-byte aligned input (n=%lld)", (long long)n);
+    hipLaunchKernelGGL(mean_sq_partial_kernel<bf16_t>, dim3(MSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scratch, n);
+    hipLaunchKernelGGL(mean_sq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, out, 1.f, accumulate);
+    VFT_CHECK_LAUNCH("vft_sum_sq_bf16");
     return 0;
 }

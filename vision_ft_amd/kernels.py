@@ -355,6 +355,26 @@ class _GateResidual(torch.autograd.Function):
         return dres, dgate, dy, None
 
 
+def clip_flat_grad_norm_(buffers: list[torch.Tensor], max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (norm type 2) when every gradient is a view into a few flat bf16 buffers
+    (trainer/dp.py): total = sqrt(sum of squares over the buffers) on vft_sum_sq_bf16 — one pass per buffer instead of a
+    multi-tensor pass over every gradient view, fp32 throughout, no ATen reduction — then
+    buffers *= min(1, max_norm / (total + 1e-6)).  Everything stays on the device (capturable).  Returns the total norm."""
+    dev = buffers[0].device
+    tot = torch.empty((), dtype=torch.float32, device=dev)
+    scratch = torch.empty(int(_C.lib().vft_mean_sq_scratch_floats()), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i, b in enumerate(buffers):
+            _require_gpu(b)
+            st = _C.lib().vft_sum_sq_bf16(_ptr(b), _ptr(tot), _ptr(scratch), b.numel(), int(i > 0), _stream())
+            _C.check(st, "vft_sum_sq_bf16")
+    norm = tot.sqrt()
+    coef = (float(max_norm) / (norm + 1e-6)).clamp(max=1.0)
+    for b in buffers:
+        b.mul_(coef.to(b.dtype))
+    return norm
+
+
 class _MeanSq(torch.autograd.Function):
     """mean(d^2) of a dense fp32 tensor (vft_mean_sq); backward 2 d g / n."""
 
@@ -1951,12 +1971,61 @@ class _Conv1x1(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.has_add and ctx.needs_input_grad[3] else None)
 
 
+class _AddChannelBias(torch.autograd.Function):
+    """h (B,C,H,W) + v broadcast over the spatial positions — v: (C,) the bias of a convolution that stays on MIOpen, or (B,C)
+    the ResidualBlock's time-embedding projection (src/models/sdxl/denoiser.py:524-551: `h + emb_out[..., None, None]`).
+    The forward is ATen's broadcast add; the BACKWARD is why this exists (round 4): autograd would sum the gradient over
+    (N,H,W) / (H,W) with ATen's long-reduction kernel — workgroups meeting through a semaphore buffer zeroed by a memset node
+    — and in replayed HIP graphs those sums came back non-finite after the process had synchronised an idle stream (24-27
+    parameters of the SDXL full fine-tune).  Here they are column sums of the channels-last gradient on vft_colsum
+    (ordered partials, no atomics, no memset)."""
+
+    @staticmethod
+    def forward(ctx, h, v):
+        ctx.per_batch = v.dim() == 2
+        ctx.vdtype = v.dtype
+        return h + (v.view(v.shape[0], v.shape[1], 1, 1) if ctx.per_batch else v.view(1, -1, 1, 1)).to(h.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        gv = None
+        if ctx.needs_input_grad[1]:
+            B, C, H, W = g.shape
+            gc = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
+            rows = gc.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            if gc.dtype != torch.bfloat16:
+                rows = rows.to(torch.bfloat16)
+            if ctx.per_batch:
+                gv = torch.stack([colsum(rows[b]) for b in range(B)]).to(ctx.vdtype)
+            else:
+                gv = colsum(rows.reshape(B * H * W, C)).to(ctx.vdtype)
+        return (g if ctx.needs_input_grad[0] else None), gv
+
+
+def add_channel_bias(h: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """h + v[..., None, None] with the gradient of v reduced by vft_colsum (see _AddChannelBias)."""
+    if not (h.is_cuda and v.requires_grad and torch.is_grad_enabled()):
+        return h + (v.view(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v.view(1, -1, 1, 1))
+    return _AddChannelBias.apply(h, v)
+
+
 def colsum(dy2: torch.Tensor, param: torch.Tensor | None = None) -> torch.Tensor | None:
     """Column sums of a (rows, C) bf16 matrix on vft_colsum — the bias gradient of a trainable projection / convolution.
     With `param` (the bias parameter) whose `.grad` is an existing dense bf16 tensor the sums are ACCUMULATED into it and
     None is returned (nothing left for autograd to add); otherwise the sums are returned in the parameter's dtype."""
     rows, C = dy2.shape
-    if (dy2.dtype != torch.bfloat16 or dy2.stride(1) != 1 or C % 8 or dy2.stride(0) % 8 or dy2.data_ptr() % 16 or rows < 1024):
+    if dy2.dtype == torch.bfloat16 and dy2.is_contiguous() and C in (1, 2, 4) and rows % (8 // C) == 0 and rows >= 8 // C:
+        # narrow tensors (the 4-channel head convolution): 8 / C consecutive rows are one 8-column row of the same memory;
+        # fold the 8 sums afterwards (a (8 / C, C) add: no reduction kernel)
+        k = 8 // C
+        folded = colsum(dy2.view(rows // k, 8), None).view(k, C)
+        out = folded[0]
+        for i in range(1, k):
+            out = out + folded[i]
+        return out if param is None else out.to(param.dtype)
+    # (round 4: no row-count threshold any more — below 1 024 rows this used to hand the sum to ATen, whose long reductions
+    #  meet through a semaphore buffer + memset node that replayed HIP graphs cannot be trusted with, DESIGN §9)
+    if (dy2.dtype != torch.bfloat16 or dy2.stride(1) != 1 or C % 8 or dy2.stride(0) % 8 or dy2.data_ptr() % 16 or rows < 1):
         out = dy2.sum(0)
         return out if param is None else out.to(param.dtype)
     g = _grad_target(param)

@@ -99,7 +99,15 @@ class ModelForTraining(ABC, nn.Module):
         cfg = self.config.trainer
         params = [p for p in self.model.parameters() if p.requires_grad]
         if cfg.clip_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(params, cfg.clip_grad_norm)
+            flat = getattr(self, "_flat_grad_buffers", None)
+            if flat and all(b.is_cuda and b.dtype == torch.bfloat16 for b in flat):
+                # every trainable gradient is a view into these buffers (trainer/dp.py; the Trainer hands them over): one
+                # pass of the own sum-of-squares kernel per buffer instead of a multi-tensor pass over every view
+                from .. import kernels
+
+                kernels.clip_flat_grad_norm_(list(flat), cfg.clip_grad_norm)
+            else:
+                torch.nn.utils.clip_grad_norm_(params, cfg.clip_grad_norm)
         if cfg.clip_grad_value is not None:
             torch.nn.utils.clip_grad_value_(params, cfg.clip_grad_value)
 

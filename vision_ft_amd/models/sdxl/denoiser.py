@@ -262,6 +262,10 @@ class _Conv2d(nn.Conv2d):
             return kernels.conv3x3(x, self.weight, self.bias)
         if kernels.conv1x1_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return kernels.conv1x1(x, self.weight, self.bias)
+        if self.bias is not None and self.bias.requires_grad and x.is_cuda and torch.is_grad_enabled() and self.padding_mode == "zeros":
+            # a TRAINABLE bias of a convolution that stays on MIOpen (stem, head, stride-2): the convolution runs without it
+            # and the bias is added by the op whose backward does not use ATen's long reduction (kernels.add_channel_bias)
+            return kernels.add_channel_bias(F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups), self.bias)
         return super().forward(x)
 
 
@@ -393,7 +397,7 @@ class ResidualBlock(nn.Module):
             residual = self.x_upd(residual)
         h = self.in_layers[2](h)
         emb = self.emb_layers[1](F.silu(embedding))
-        h = h + emb.view(emb.shape[0], emb.shape[1], 1, 1)
+        h = kernels.add_channel_bias(h, emb)  # h + emb[:, :, None, None]; the (H, W) sum of its gradient on vft_colsum
         h = self.out_layers[0](h)  # GroupNorm + SiLU (fused)
         h = self.out_layers[3](self.out_layers[2](h))
         skip = self.skip_connection

@@ -137,6 +137,8 @@ class Trainer:
     def prepare_optimizer(self) -> None:
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.dp = DataParallelGrads(params)
+        # gradient-norm clipping reduces over these buffers directly (ModelForTraining.after_backward)
+        getattr(self, "raw_model", self.model)._flat_grad_buffers = list(self.dp.flat.buffers.values())
         args = dict(self.config.optimizer.args)
         if self.config.trainer.hip_graph and torch.cuda.is_available() and _accepts_capturable(self.config.optimizer.name):
             args.setdefault("capturable", True)
