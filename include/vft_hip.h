@@ -193,6 +193,10 @@ int vft_norm_bwd_params(const void* dy, const void* x, const void* scale, const 
  * vft_norm_bwd_params_scratch_floats(rows, C) floats.  Ordered partial sums, bit-reproducible. */
 int vft_colsum(const void* dy, void* out, float* scratch, int64_t rows, int C, int64_t ld, int accumulate, int out_f32,
                void* stream);
+/* out[b][c] = sum over the rows of batch element b of dy[b][row][c] (dy dense [B][rows][ld]): the gradient of a per-sample channel
+ * vector broadcast over the spatial positions — the ResidualBlock's time-embedding projection, src/models/sdxl/denoiser.py:524-551
+ * (autograd: aten::sum over H, W).  One launch pair for the whole batch; scratch: B x vft_norm_bwd_params_scratch_floats(rows, C). */
+int vft_colsum_batched(const void* dy, void* out, float* scratch, int B, int64_t rows, int C, int64_t ld, int out_f32, void* stream);
 
 /* ---- per-head q/k norm + RoPE ---------------------------------------------------------------
  * x: (B,S,H,D) bf16 addressed by x_strides[3] = {batch, seq, head} (so views into a fused qkv

@@ -369,3 +369,26 @@ def test_flat_gradient_clipping_matches_torch(gpu):
         assert abs(float(got_norm) - float(want_norm)) < 1e-4 * float(want_norm)
         for b, p_ in zip(bufs, params):
             assert rel_err(b.float().cpu(), p_.grad.cpu()) < 4e-3
+
+
+@pytest.mark.parametrize("shape,per_batch", [((3, 64, 20, 12), True), ((2, 320, 40, 40), True), ((2, 4, 32, 32), False), ((3, 24, 9, 7), False)])
+def test_add_channel_bias_gradients(gpu, shape, per_batch):
+    """kernels.add_channel_bias: h + v[..., None, None] with the gradient of v from vft_colsum / vft_colsum_batched (per-sample
+    vector: the ResidualBlock's time embedding; per-channel vector: the bias of a convolution that stays on MIOpen, incl. the
+    4-channel head) against autograd's broadcast add."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(17)
+    B, C, H, W = shape
+    h = torch.randn(*shape, generator=g).to(torch.bfloat16).to(gpu).contiguous(memory_format=torch.channels_last)
+    v = torch.randn((B, C) if per_batch else (C,), generator=g).to(torch.bfloat16).to(gpu)
+    dy = torch.randn(*shape, generator=g).to(torch.bfloat16).to(gpu).contiguous(memory_format=torch.channels_last)
+    hh, vv = h.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    out = kernels.add_channel_bias(hh, vv)
+    out.backward(dy)
+    hr, vr = h.float().requires_grad_(True), v.float().requires_grad_(True)
+    ref = hr + (vr.view(B, C, 1, 1) if per_batch else vr.view(1, C, 1, 1))
+    ref.backward(dy.float())
+    assert rel_err(out.float().cpu(), ref.detach().cpu()) < 4e-3
+    assert torch.equal(hh.grad, dy)
+    assert rel_err(vv.grad.float().cpu(), vr.grad.cpu()) < 6e-3, rel_err(vv.grad.float().cpu(), vr.grad.cpu())

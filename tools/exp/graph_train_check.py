@@ -1,5 +1,5 @@
 """Round 4: does an idle-stream synchronize before graph replays change what the replays COMPUTE (not just the reported loss)?
-   python tools/exp/graph_train_check.py eager|graph|graph_sync <out.pt>     (6 optimizer steps of SDXL-LoRA at B=8)"""
+   python tools/exp/graph_train_check.py eager|graph|graph_sync <out.pt> [B] [workload]     (6 optimizer steps at batch B of a bench workload; default SDXL-LoRA at B=8)"""
 import sys
 
 import torch
@@ -9,16 +9,17 @@ import bench  # noqa: E402
 
 mode, out = sys.argv[1], sys.argv[2]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+WL = sys.argv[4] if len(sys.argv) > 4 else "sdxl_lora"
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 from vision_ft_amd.trainer.dp import DataParallelGrads  # noqa: E402
 from vision_ft_amd.trainer.graph import GraphedTrainStep  # noqa: E402
 
-model = bench.build("sdxl_lora", dev)
+model = bench.build(WL, dev)
 params = [p for p in model.parameters() if p.requires_grad]
 dp = DataParallelGrads(params)
 opt = torch.optim.AdamW(params, lr=1e-3, fused=True, capturable=True)
-fwd = bench.make_step("sdxl_lora", model, dev, B, seed=42)
+fwd = bench.make_step(WL, model, dev, B, seed=42)
 losses = []
 if mode == "eager":
     for i in range(6):

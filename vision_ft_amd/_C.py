@@ -62,6 +62,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_conv3x3_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "vft_norm_bwd_params_scratch_floats": (c_int64, [c_int64, c_int]),
     "vft_colsum": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
+    "vft_colsum_batched": (c_int, [c_void_p] * 3 + [c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
     "vft_norm_bwd_params": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vft_qk_norm_rope_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [_I64P, c_int64, c_int, c_float, c_void_p]),
     "vft_qk_norm_rope_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [_I64P, _I64P, c_int64, c_int, c_void_p]),

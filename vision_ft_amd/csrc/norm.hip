@@ -214,6 +214,7 @@ struct NormParamGrad {
     int C;
     int64_t ldx, lddy;
     int rpb, kind, slab_rows, slabs, out_f32, accumulate;
+    int64_t dy_bs, part_bs, out_bs;  // batched column sums (vft_colsum_batched): element strides per blockIdx.z; 0 otherwise
 };
 
 __global__ __launch_bounds__(256) void norm_bwd_params_partial_kernel(NormParamGrad p) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void norm_bwd_params_partial_kernel(NormParamG
     if (col < p.C) {
         auto one = [&](int64_t r) {
             float xv[8], g[8];
-            load8(p.dy + r * p.lddy + col, g);
+            load8(p.dy + (int64_t)blockIdx.z * p.dy_bs + r * p.lddy + col, g);
             if (p.x == nullptr) {  // column sums only (vft_colsum)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ab[i] += g[i];
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void norm_bwd_params_partial_kernel(NormParamG
         float sw = 0.f, sb = 0.f;
 #pragma unroll
         for (int l = 0; l < 8; ++l) sw += red[0][l][threadIdx.x], sb += red[1][l][threadIdx.x];
-        float* o = p.part + (int64_t)blockIdx.y * 2 * p.C;
+        float* o = p.part + (int64_t)blockIdx.z * p.part_bs + (int64_t)blockIdx.y * 2 * p.C;
         o[c] = sw;
         o[p.C + c] = sb;
     }
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(1024) void norm_bwd_params_reduce_kernel(NormParamG
     const int c = blockIdx.x * 64 + cl;
     float a = 0.f;
     if (c < p.C)
-        for (int s = sl; s < p.slabs; s += 16) a += p.part[((int64_t)s * 2 + blockIdx.y) * p.C + c];
+        for (int s = sl; s < p.slabs; s += 16) a += p.part[(int64_t)blockIdx.z * p.part_bs + ((int64_t)s * 2 + blockIdx.y) * p.C + c];
     red[sl][cl] = a;
     __syncthreads();
     if (sl == 0 && c < p.C) {
@@ -285,8 +286,9 @@ __global__ __launch_bounds__(1024) void norm_bwd_params_reduce_kernel(NormParamG
         for (int l = 0; l < 16; ++l) t += red[l][cl];
         void* out = blockIdx.y == 0 ? p.dw : p.db;
         if (out != nullptr) {
-            if (p.out_f32) ((float*)out)[c] = t + (p.accumulate ? ((float*)out)[c] : 0.f);
-            else ((bf16_t*)out)[c] = (bf16_t)(t + (p.accumulate ? (float)((bf16_t*)out)[c] : 0.f));
+            const int64_t oc = (int64_t)blockIdx.z * p.out_bs + c;
+            if (p.out_f32) ((float*)out)[oc] = t + (p.accumulate ? ((float*)out)[oc] : 0.f);
+            else ((bf16_t*)out)[oc] = (bf16_t)(t + (p.accumulate ? (float)((bf16_t*)out)[oc] : 0.f));
         }
     }
 }
@@ -558,6 +560,27 @@ extern "C" int vft_colsum(const void* dy, void* out, float* scratch, int64_t row
                        (hipStream_t)stream, p);
     hipLaunchKernelGGL(norm_bwd_params_reduce_kernel, dim3((unsigned)((C + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream, p);
     VFT_CHECK_LAUNCH("vft_colsum");
+    return 0;
+}
+
+// out[b][c] = sum over the rows of batch element b of dy[b][row][c] (dy: [B][rows][ld >= C] bf16, dense batches): the gradient of a
+// per-sample channel vector that was broadcast over the spatial positions — the ResidualBlock's time-embedding projection
+// (src/models/sdxl/denoiser.py:524-551, `h + emb_out[..., None, None]`; autograd: aten::sum over H, W).  One launch pair for the
+// whole batch (blockIdx.z); scratch: B x vft_norm_bwd_params_scratch_floats(rows, C) floats.  Ordered partial sums.
+extern "C" int vft_colsum_batched(const void* dy, void* out, float* scratch, int B, int64_t rows, int C, int64_t ld, int out_f32,
+                                  void* stream) {
+    VFT_CHECK_ARG(dy && out && scratch, "vft_colsum_batched: null pointer");
+    VFT_CHECK_ARG(B > 0 && B < 65536 && rows > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && ld >= C, "vft_colsum_batched: unsupported B=%d C=%d", B, C);
+    VFT_CHECK_ARG(((uintptr_t)dy & 15) == 0, "vft_colsum_batched: misaligned pointer");
+    NormParamGrad p{};
+    p.dy = (const bf16_t*)dy, p.part = scratch, p.db = out, p.rows = rows, p.C = C, p.lddy = ld, p.rpb = 1;
+    p.out_f32 = out_f32, p.accumulate = 0;
+    norm_param_slabs(rows, C, p.slab_rows, p.slabs);
+    p.dy_bs = rows * ld, p.part_bs = (int64_t)p.slabs * 2 * C, p.out_bs = C;
+    hipLaunchKernelGGL(norm_bwd_params_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)p.slabs, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(norm_bwd_params_reduce_kernel, dim3((unsigned)((C + 63) / 64), 2, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, p);
+    VFT_CHECK_LAUNCH("vft_colsum_batched");
     return 0;
 }
 

@@ -1995,7 +1995,15 @@ class _AddChannelBias(torch.autograd.Function):
             rows = gc.permute(0, 2, 3, 1).reshape(B, H * W, C)
             if gc.dtype != torch.bfloat16:
                 rows = rows.to(torch.bfloat16)
-            if ctx.per_batch:
+            if ctx.per_batch and C % 8 == 0 and rows.is_contiguous() and rows.data_ptr() % 16 == 0:
+                lib = _C.lib()
+                gv = torch.empty((B, C), dtype=torch.bfloat16, device=g.device)
+                scratch = torch.empty(B * int(lib.vft_norm_bwd_params_scratch_floats(H * W, C)), dtype=torch.float32, device=g.device)
+                with torch.cuda.device(g.device), _Timed("colsum", 2.0 * B * H * W * C):
+                    st = lib.vft_colsum_batched(_ptr(rows), _ptr(gv), _ptr(scratch), B, H * W, C, C, 0, _stream())
+                _C.check(st, "vft_colsum_batched")
+                gv = gv.to(ctx.vdtype)
+            elif ctx.per_batch:
                 gv = torch.stack([colsum(rows[b]) for b in range(B)]).to(ctx.vdtype)
             else:
                 gv = colsum(rows.reshape(B * H * W, C)).to(ctx.vdtype)
