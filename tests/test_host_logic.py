@@ -434,3 +434,37 @@ def test_bench_gpus_n_starts_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env2, cwd=root,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=3" in (r2.stderr + r2.stdout)
+
+
+def test_bench_line_stays_compact():
+    """The ONE line bench.py prints must stay far below what a driver captures of stdout (round 3's 34 KB line could not be
+    parsed): the compaction keeps the contract's keys and one [ms, fraction] pair per kernel family, whatever the detail holds."""
+    import importlib.util
+    import json
+    import os
+
+    spec = importlib.util.spec_from_file_location("vft_bench_c", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fam = {k: {"kernel": v[1], "bound": v[2], "ms_per_step": 12.345, "launches_per_step": 100, "achieved": 1234.5, "unit": "TFLOP/s",
+               "frac": 0.4938, "avg_launch_us": 123.4, "work_per_launch": 1.0} for k, v in bench.FAMILIES.items()}
+    roof = {"bound": "mfma", "kernel": bench.FAMILIES["linear_gemm"][1], "family": "linear_gemm", "achieved": 1234.5, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": 0.4938, "traffic": 1557600000, "traffic_note": "x" * 400, "avg_launch_us": 188.6, "launches_per_step": 973, "share_of_step": 0.37,
+            "families": fam, "hand_written_ms_per_step": 440.0, "library_and_aten_ms_per_step": 10.0, "eager_pass_ms_per_step": 2000.0,
+            "kernel_ms_per_step": {f"k{i}": 1.0 for i in range(60)}, "per_call": {f"k{i}": {"bound": "hbm", "achieved": 1, "unit": "GB/s", "frac": 0.5} for i in range(60)},
+            "measured": "HIP events around each launch, eager pass after the graph-replayed timed region", "step_mfma_frac": 0.288}
+    cfg = {"workload": "sdxl_lora", "resolution": "1024x1024", "per_gpu_batch": 24, "global_batch": 24, "parallelism": "dp1", "optimizer": "AdamW(fused, lr=0.001)",
+           "hip_graph": True, "gemm_table": True, "lora_in_gemm": True, "trainable_params": 10465280, "loss": 1.01, "peak_mem_gib": 145.8,
+           "algorithmic_tflop_per_image": 13.5, "base_weights": "NF4 (blocksize 64, double-quantised absmax): the only copy in HBM ...", "caption_lengths": "256 (fixed)"}
+    line = {"metric": "train images/sec at 1024^2", "value": 53.3, "unit": "images/s", "n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": 449.9,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": bench.compact_config(cfg), "roofline": bench.compact_roofline(roof),
+            "workloads": {f"leg{i}": {"value": 9.9, "ms_per_step": 600.0, "per_gpu_batch": 6, "step_mfma_frac": 0.35, "dominant": "linear_gemm",
+                                      "dominant_frac": 0.6, "dominant_share": 0.47} for i in range(8)},
+            "cpu_baseline": {"value": 0.04, "unit": "images/s", "cores": 128, "kind": "port", "sample": "y" * 250}, "detail_file": "gpurun_out/bench_detail_n1.json"}
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "family"):
+        assert key in line["roofline"]
+    assert set(line["roofline"]["families_ms_frac"]) == set(bench.FAMILIES)
+    assert "per_call" not in line["roofline"] and "kernel_ms_per_step" not in line["roofline"]
