@@ -371,7 +371,7 @@ def clip_flat_grad_norm_(buffers: list[torch.Tensor], max_norm: float) -> torch.
     norm = tot.sqrt()
     coef = (float(max_norm) / (norm + 1e-6)).clamp(max=1.0)
     for b in buffers:
-        b.mul_(coef.to(b.dtype))
+        b.mul_(coef)  # a 0-dim fp32 factor: the product is formed in fp32 and rounded once, like torch's clip_grad_norm_
     return norm
 
 
