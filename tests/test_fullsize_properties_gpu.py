@@ -244,3 +244,43 @@ def test_non_square_bucket_at_full_size(gpu, hw):
         assert rel_err(c_, a_.float() + b_.float()) < 1.5e-2
     (dv,) = torch.autograd.grad(o, (v,), torch.ones_like(o))
     assert rel_err(dv.float().sum(2), torch.full((Bh, Hh, D), float(S), device=gpu)) < 5e-3
+
+
+def test_round4_kernels_at_bench_size(gpu):
+    """Round 4 at the bench's sizes: (a) the NF4 launch that dequantises once equals — bit for bit — the bf16 projection GEMM on
+    the image it builds, at Lumina2's M = 17 408 (split launches of the tile table included), forward and data gradient, and is
+    bit-reproducible; (b) the head_dim 64 / 96 forward on the LDS-DMA operand path agrees with the round-1 kernel (two
+    roundings of the same softmax) at SDXL's and Lumina2's shapes, key mask included, and satisfies the row-sum property."""
+    from vision_ft_amd import _C, kernels
+    from vision_ft_amd.modules.quant import NF4Linear, quantize_nf4
+
+    M, out_f, in_f = 17408, 3840, 2304
+    q = quantize_nf4(torch.randn(out_f, in_f) * in_f**-0.5, double_quant=True)
+    layer = NF4Linear(in_f, out_f, bias=False)
+    layer.load_state_dict({"weight" + k: v for k, v in q.items()}, strict=True)
+    layer = layer.to(gpu)
+    qs = layer.quant_state()
+    pk = qs.packed.view(-1).long()
+    idx = torch.stack([pk >> 4, pk & 15], dim=1).view(-1)
+    dense = (qs.code.float()[idx] * qs.absmax_f32().repeat_interleave(64)).to(torch.bfloat16).view(out_f, in_f)
+    x, dy = _bf(gpu, M, in_f, seed=21), _bf(gpu, M, out_f, seed=22)
+    assert kernels.NF4_DEQUANT_ONCE
+    y = kernels._nf4_gemm(x, qs, None, False)
+    assert torch.equal(y, kernels.linear_fused(x, dense)) and torch.equal(y, kernels._nf4_gemm(x, qs, None, False))
+    dx = kernels._nf4_gemm(dy, qs, None, True)
+    assert torch.equal(dx, kernels.linear_fused(dy, dense.t().contiguous()))
+    assert not kernels.nf4_barrier_timed_out()
+
+    for (B, Hq, Hkv, S, D, lens) in ((4, 10, 10, 4096, 64, None), (2, 24, 8, 4352, 96, [4352, 4141])):
+        qq = _bf(gpu, B, S, Hq, D, seed=31).permute(0, 2, 1, 3)
+        kk, vv = _bf(gpu, B, S, Hkv, D, seed=32).permute(0, 2, 1, 3), _bf(gpu, B, S, Hkv, D, seed=33).permute(0, 2, 1, 3)
+        kv = torch.tensor(lens, dtype=torch.int32, device=gpu) if lens else None
+        try:
+            new = kernels.flash_attention(qq, kk, vv, kv_len=kv)
+            _C.lib().vft_attn_variant(1)
+            old = kernels.flash_attention(qq, kk, vv, kv_len=kv)
+        finally:
+            _C.lib().vft_attn_variant(0)
+        assert rel_err(new.float(), old.float()) < 5e-3, (D, rel_err(new.float(), old.float()))
+        ones = torch.ones(B, S, Hkv, D, device=gpu, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+        assert (kernels.flash_attention(qq, kk, ones, kv_len=kv).float() - 1).abs().max() < 2e-2
