@@ -247,7 +247,7 @@ def compact_roofline(r: dict) -> dict:
 
 def compact_config(c: dict) -> dict:
     keep = ("workload", "resolution", "per_gpu_batch", "global_batch", "parallelism", "optimizer", "hip_graph", "trainable_params", "loss",
-            "peak_mem_gib", "algorithmic_tflop_per_image", "use_rope", "lora_key_set", "caption_lengths")
+            "peak_mem_gib", "algorithmic_tflop_per_image", "use_rope", "lora_key_set", "caption_lengths", "nf4_barrier_timed_out")
     out = {k: c[k] for k in keep if k in c}
     if "base_weights" in c:
         out["base_weights"] = "NF4 in HBM, dequantised in the GEMM kernel" if "only copy" in c["base_weights"] else "NF4 state, bf16 compute cache (labelled option)"
@@ -536,7 +536,9 @@ def main():
                                "module state / checkpoint format; compute on a dequantised bf16 cache (VFT_NF4_CACHE=1: NOT the "
                                "config as BASELINE states it — a labelled memory-for-speed option)"
                                if _nf4_cache_on() else "the only copy in HBM, dequantised inside the GEMM kernel (VFT_NF4_CACHE=0, default)"),
-                               "caption_lengths": "U{32..256} drawn per step on the device, shape-static forward" if drawn_lengths else "256 (fixed)"}
+                               "caption_lengths": "U{32..256} drawn per step on the device, shape-static forward" if drawn_lengths else "256 (fixed)",
+                               # (the dequantising launch's grid barrier has a bounded wait: did any launch give up on it?)
+                               "nf4_barrier_timed_out": bool(kernels.nf4_barrier_timed_out())}
                               if workload.startswith("lumina") else {}),
                            **({"use_rope": use_rope, "lora_key_set": "configs/auraflow/lora.yml (124 Linears)" if aura_keys == "yaml124"
                                else "tests/assets/debug_dataset.yml (252 Linears)"} if workload.startswith("aura") else {})},
