@@ -468,3 +468,20 @@ def test_bench_line_stays_compact():
         assert key in line["roofline"]
     assert set(line["roofline"]["families_ms_frac"]) == set(bench.FAMILIES)
     assert "per_call" not in line["roofline"] and "kernel_ms_per_step" not in line["roofline"]
+
+
+def test_split_last_returns_views_and_one_concatenated_gradient():
+    """kernels.split_last (Lumina2's q | k | v views of the fused projection output as one autograd node): views of the
+    input, gradients side by side, a piece nobody used contributes zeros — same numbers as three plain slices."""
+    import torch
+
+    from vision_ft_amd import kernels
+
+    x = torch.randn(2, 5, 12, requires_grad=True)
+    a, b, c = kernels.split_last(x, (6, 3, 3))
+    assert a.shape == (2, 5, 6) and b.shape == (2, 5, 3) and c.data_ptr() == x.data_ptr() + 9 * 4
+    wa, wc = torch.randn(2, 5, 6), torch.randn(2, 5, 3)
+    ((a * wa).sum() + (c * wc).sum()).backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    ((x2[..., :6] * wa).sum() + (x2[..., 9:] * wc).sum()).backward()
+    assert torch.equal(x.grad, x2.grad)

@@ -321,6 +321,40 @@ def rms_norm_scale(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor | 
     return _norm(x, weight, None, scale, None, KIND_RMS, eps)
 
 
+def rms_norm_scale_skip(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor | None, eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """(rms_norm_scale(x, ...), x): the second output carries the block's residual path (Lumina2: `x + tanh(g) * norm2(branch(norm1(x)))`,
+    src/models/lumina2/denoiser.py:216-258), so that its gradient meets the norm's own inside the norm-backward kernel instead
+    of in an autograd accumulation add (one elementwise pass over the hidden state per norm)."""
+    return _norm(x, weight, None, scale, None, KIND_RMS, eps, skip=True)
+
+
+class _SplitLast(torch.autograd.Function):
+    """x[..., a:b] views of a fused projection output (Lumina2's q | k | v, src/models/lumina2/denoiser.py:96-112) as ONE autograd
+    node: the backward writes the pieces' gradients side by side in one pass (a concatenation), where three slice nodes each
+    embed their gradient in a zero-filled full-size tensor and autograd adds the three (3 fills + 3 copies + 2 adds of the
+    (tokens, 3840) matrix per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.sizes = sizes
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return tuple(x.split(list(sizes), dim=-1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        parts = []
+        for g, n in zip(grads, ctx.sizes):
+            if g is None:
+                g = torch.zeros((*ctx.shape[:-1], n), dtype=ctx.dtype, device=next(t for t in grads if t is not None).device)
+            parts.append(g.to(ctx.dtype))
+        return (torch.cat(parts, dim=-1), *([None] * len(ctx.sizes)))
+
+
+def split_last(x: torch.Tensor, sizes) -> tuple[torch.Tensor, ...]:
+    """Views x[..., :s0], x[..., s0:s0+s1], ... whose gradients come back as one concatenated tensor (see `_SplitLast`)."""
+    return _SplitLast.apply(x, *[int(n) for n in sizes])
+
+
 class _GateResidual(torch.autograd.Function):
     @staticmethod
     def forward(ctx, residual, gate, y, use_tanh):

@@ -18,6 +18,7 @@ Execution differences (same results):
 from __future__ import annotations
 
 import math
+import os
 from typing import NamedTuple
 
 import torch
@@ -31,6 +32,11 @@ from ...modules.norm import FP32LayerNorm
 from ...modules.timestep.embedding import get_timestep_embedding
 from ...utils.tensor import module_dtype
 from .config import DenoiserConfig
+
+# A/B switch.  1 (default): the q | k | v views of the fused projection are one autograd node (their gradients return as one
+# concatenated tensor) and a block's input reaches its gated add through the pre-norm's second output (the two gradients of the
+# input meet inside the norm-backward kernel).  0: plain slices and plain fan-out, summed by autograd's elementwise passes.
+GRAD_FUSION = os.environ.get("VFT_LUMINA_GRAD_FUSION", "1") != "0"
 
 DENOISER_TENSOR_PREFIX = "model.diffusion_model."
 
@@ -91,9 +97,14 @@ class SelfAttention(nn.Module):
         qkv = self.qkv(hidden_states)
         D = self.head_dim
         # strided views into the fused projection output: no split copies
-        q = qkv[..., : self.q_dim].unflatten(-1, (self.num_heads, D))
-        k = qkv[..., self.q_dim : self.q_dim + self.k_dim].unflatten(-1, (self.num_kv_heads, D))
-        v = qkv[..., self.q_dim + self.k_dim :].unflatten(-1, (self.num_kv_heads, D))
+        # (one autograd node for the three views: their gradients come back side by side in one pass)
+        if GRAD_FUSION:
+            q, k, v = kernels.split_last(qkv, (self.q_dim, self.k_dim, self.v_dim))
+        else:
+            q, k, v = qkv.split([self.q_dim, self.k_dim, self.v_dim], dim=-1)
+        q = q.unflatten(-1, (self.num_heads, D))
+        k = k.unflatten(-1, (self.num_kv_heads, D))
+        v = v.unflatten(-1, (self.num_kv_heads, D))
         q = kernels.qk_norm_rope(q, "rms", self.q_norm.weight, 1e-6, freqs_cis.cos, freqs_cis.sin)
         k = kernels.qk_norm_rope(k, "rms", self.k_norm.weight, 1e-6, freqs_cis.cos, freqs_cis.sin)
         attn = scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask=mask,
@@ -148,15 +159,24 @@ class TransformerBlock(nn.Module):
     def _norm(self, norm: nn.RMSNorm, x: torch.Tensor, scale: torch.Tensor | None = None) -> torch.Tensor:
         return kernels.rms_norm_scale(x, norm.weight, scale, norm.eps)
 
+    def _norm_skip(self, norm: nn.RMSNorm, x: torch.Tensor, scale: torch.Tensor | None = None):
+        """(norm(x), x) with the second output carrying the residual path (kernels.rms_norm_scale_skip)."""
+        if GRAD_FUSION and x.is_cuda:
+            return kernels.rms_norm_scale_skip(x, norm.weight, scale, norm.eps)
+        return self._norm(norm, x, scale), x
+
     def forward(self, hidden_states: torch.Tensor, freqs_cis: Rope, adaln_input: torch.Tensor | None = None,
                 mask: torch.Tensor | None = None, kv_len: torch.Tensor | None = None) -> torch.Tensor:
         x = hidden_states
         if self.use_adaln:
             assert adaln_input is not None, "adaln_input must be provided for AdaLN"
             sc_a, g_a, sc_m, g_m = self.adaLN_modulation(adaln_input).chunk(4, dim=1)
-            a = self.attention(self._norm(self.attention_norm1, x, sc_a), freqs_cis, mask=mask, kv_len=kv_len)
+            # the block input feeds norm1 and the gated add: the two gradients meet inside norm1's backward kernel
+            n, x = self._norm_skip(self.attention_norm1, x, sc_a)
+            a = self.attention(n, freqs_cis, mask=mask, kv_len=kv_len)
             x = kernels.gate_residual(x, g_a, self._norm(self.attention_norm2, a), tanh=True)
-            m = self.feed_forward(self._norm(self.ffn_norm1, x, sc_m))
+            n, x = self._norm_skip(self.ffn_norm1, x, sc_m)
+            m = self.feed_forward(n)
             return kernels.gate_residual(x, g_m, self._norm(self.ffn_norm2, m), tanh=True)
         a = self.attention(self._norm(self.attention_norm1, x), freqs_cis, mask=mask, kv_len=kv_len)
         x = x + self._norm(self.attention_norm2, a)
