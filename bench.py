@@ -312,6 +312,18 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def claim_stdout():
+    """Keep STDOUT for the result line alone: returns a handle on the real stdout and points file descriptor 1 at stderr for
+    everything else in this process — native libraries included.  RCCL writes a five-line version banner to STDOUT when the
+    first communicator is created (`RCCL version : ... Librccl path : ...`, measured on the MI355X box with
+    tools/exp/rccl_banner.py; only NCCL_DEBUG=NONE silences it), in EVERY rank, and torch.distributed.run forwards every rank's
+    stdout — the driver reads ONE JSON line there."""
+    sys.stdout.flush()
+    keep = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +352,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    result_out = claim_stdout()  # from here on fd 1 is stderr; rank 0 writes its one line to `result_out`
     if args.launch_selftest:
         # host-only rehearsal of the launch path (tests/test_host_logic.py, no GPU): process group, barrier, the MAX
         # reduction the timing uses, one JSON line from rank 0
@@ -348,18 +361,25 @@ def main():
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
-            print(json.dumps({"selftest": "launch", "n_gpus": world, "max_over_ranks": float(t.item())}))
+            result_out.write(json.dumps({"selftest": "launch", "n_gpus": world, "max_over_ranks": float(t.item())}) + "\n")
+            result_out.flush()
         dist.destroy_process_group()
         return
     # (test hooks: VFT_FORCE_DEVICE / VFT_DIST_BACKEND=gloo let two ranks share one GPU to rehearse the N>1 path)
     device = torch.device("cuda", int(os.environ.get("VFT_FORCE_DEVICE", local)))
     torch.cuda.set_device(device)
-    if world > 1:
+    one_rank_group = world == 1 and os.environ.get("VFT_DP_ALWAYS_REDUCE", "0") == "1"  # rehearsal hook, trainer/dp.py
+    if world > 1 or one_rank_group:
         backend = os.environ.get("VFT_DIST_BACKEND", "nccl")
+        kw = {}
+        if one_rank_group:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            kw = {"rank": 0, "world_size": 1}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
 
     from vision_ft_amd import kernels, tuning
     from vision_ft_amd.trainer.dp import DataParallelGrads
@@ -372,7 +392,7 @@ def main():
     default_batch = {"sdxl_lora": 24, "sdxl_full": 24, "aura_lora": 6, "lumina_lora": 4, "lumina_qlora": 4, "sdxl_buckets": 16}
 
     def fence():
-        if world > 1:
+        if world > 1 or one_rank_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -484,7 +504,7 @@ def main():
             eager_ms = e0.elapsed_time(e1) / prof_steps
         prof = kernels.profile_report() if rank == 0 else {}
         kernels.set_profiling(False)
-        if world > 1:
+        if world > 1 or one_rank_group:
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -527,7 +547,7 @@ def main():
             res = {
                 "value": round(images_s, 3), "ms_per_step": round(ms_per_step, 2),
                 "config": {"workload": workload, "resolution": "mixed buckets ~1 MP" if bucket_note else "1024x1024", "per_gpu_batch": batch,
-                           "global_batch": batch * world, "parallelism": f"dp{world}", "optimizer": f"AdamW(fused, lr={lr:g})", "hip_graph": use_graph,
+                           "global_batch": batch * world, "parallelism": f"dp{world}" + (" (rehearsal: one-rank process group, gradients through the backend's all-reduce)" if one_rank_group else ""), "optimizer": f"AdamW(fused, lr={lr:g})", "hip_graph": use_graph,
                            "gemm_table": bool(gemm_table), "lora_in_gemm": bool(kernels.FUSED_LORA_GEMM),
                            "trainable_params": sum(p.numel() for p in params), "loss": round(last_loss, 5),
                            "peak_mem_gib": round(peak_timed, 1), "algorithmic_tflop_per_image": F_ALG[workload],
@@ -608,8 +628,9 @@ def main():
             out["cpu_baseline"] = cpu
         out["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path else "stderr"
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
+    if world > 1 or one_rank_group:
         dist.destroy_process_group()
 
 

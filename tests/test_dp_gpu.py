@@ -96,6 +96,61 @@ def test_two_ranks_on_one_gpu_match_the_mean_gradient_run(gpu, tmp_path):
         assert all(torch.isfinite(torch.tensor(graph[r]["losses"])))
 
 
+def _one_rank(tmp_path, tag, hip_graph, always_reduce):
+    from .dp_rehearsal_worker import run_one_rank_backend_group
+
+    out = tmp_path / tag
+    out.mkdir()
+    ctx = multiprocessing.get_context("forkserver")
+    p = ctx.Process(target=run_one_rank_backend_group, args=(str(out), hip_graph, "nccl", always_reduce))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0, p.exitcode
+    return torch.load(out / "result.pt")
+
+
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_one_rank_rccl_group_takes_the_same_steps(gpu, tmp_path, hip_graph):
+    """The RCCL call path of the data-parallel step on the one GPU there is: a one-rank `nccl` process group with
+    VFT_DP_ALWAYS_REDUCE=1 sends every step's flat gradient buffer through RCCL's all-reduce on the side stream (pre-scaled
+    by 1 / 1; the identity) and, in graph mode, runs the split-graph form of the N > 1 step.  Same data, same seeds as the
+    plain single-GPU run => the same losses and weights (within the run-to-run noise of the tiny model's library GEMMs), and
+    a buffer of known numbers comes back from the exchange bit for bit."""
+    plain = _one_rank(tmp_path, "plain", hip_graph, always_reduce=False)
+    rccl = _one_rank(tmp_path, "rccl", hip_graph, always_reduce=True)
+    assert not plain["collective"] and plain["group"] is False
+    assert rccl["collective"] and rccl["group"] == "nccl" and rccl["steps"] == plain["steps"] == 6
+    assert rccl["identity"] is True  # known numbers through the side-stream all-reduce: every bit back
+    # (the tiny model's conditioning GEMMs are library calls whose reductions are not run-to-run reproducible, and Adam
+    #  amplifies their last bits: equal within that noise, as in the two-rank rehearsal above)
+    assert rccl["losses"][0] == plain["losses"][0]  # no update yet: the same kernels on the same inputs
+    torch.testing.assert_close(torch.tensor(rccl["losses"]), torch.tensor(plain["losses"]), rtol=5e-3, atol=1e-4)
+    assert _dist(rccl["lora"], plain["lora"]) < 3e-2, _dist(rccl["lora"], plain["lora"])
+    assert any(v.abs().sum() > 0 for k, v in rccl["lora"].items() if "lora_up" in k)
+
+
+def test_bench_line_is_alone_on_stdout_with_rccl(tmp_path):
+    """RCCL prints a version banner on STDOUT when its first communicator is created (five lines per rank); bench.py keeps
+    stdout for its one JSON line (`claim_stdout`).  Run inside a one-rank `nccl` group: the banner must have gone to stderr,
+    stdout must be exactly the line, and the line must say that the gradients went through the backend."""
+    import json
+
+    from .dp_rehearsal_worker import run_bench_in_one_rank_rccl_group
+
+    out = tmp_path / "bench_rccl.json"
+    ctx = multiprocessing.get_context("forkserver")
+    p = ctx.Process(target=run_bench_in_one_rank_rccl_group, args=(str(out),))
+    p.start()
+    p.join(timeout=1000)
+    assert p.exitcode == 0
+    res = json.loads(out.read_text())
+    assert res["rc"] == 0, res["stderr"][-3000:]
+    lines = [ln for ln in res["stdout"].splitlines() if ln.strip()]
+    assert len(lines) == 1, res["stdout"][:2000]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and "one-rank process group" in line["config"]["parallelism"] and line["value"] > 0
+
+
 def test_bench_gpus_2_self_launch(tmp_path):
     """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) starts its two ranks itself and prints ONE JSON line with
     n_gpus = 2 and the whole-job rate.  Rehearsed on the one GPU (both ranks on cuda:0, gloo transport): everything of the
@@ -112,7 +167,7 @@ def test_bench_gpus_2_self_launch(tmp_path):
     assert p.exitcode == 0
     res = json.loads(out.read_text())
     assert res["rc"] == 0, res["stderr"]
-    lines = [ln for ln in res["stdout"].splitlines() if ln.startswith("{")]
+    lines = [ln for ln in res["stdout"].splitlines() if ln.strip()]  # nothing but the line on stdout
     assert len(lines) == 1, res["stdout"][-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"

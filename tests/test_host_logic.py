@@ -425,7 +425,7 @@ def test_bench_gpus_n_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]  # stdout carries the line and nothing else (bench.claim_stdout)
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out == {"selftest": "launch", "n_gpus": 2, "max_over_ranks": 2.0}
@@ -485,3 +485,20 @@ def test_split_last_returns_views_and_one_concatenated_gradient():
     x2 = x.detach().clone().requires_grad_(True)
     ((x2[..., :6] * wa).sum() + (x2[..., 9:] * wc).sum()).backward()
     assert torch.equal(x.grad, x2.grad)
+
+
+def test_claim_stdout_diverts_native_writes():
+    """bench.claim_stdout: after it, anything written to file descriptor 1 — Python prints and native libraries alike (RCCL's
+    version banner is a printf) — lands on stderr, and only what is written to the returned handle reaches the real stdout."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; out = bench.claim_stdout(); "
+            "os.write(1, b'native banner\\n'); print('python print'); sys.stdout.flush(); "
+            "out.write('{\"the\": \"line\"}\\n'); out.flush()" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == '{"the": "line"}\n'
+    assert "native banner" in r.stderr and "python print" in r.stderr

@@ -69,6 +69,11 @@ def init_distributed() -> None:
         torch.cuda.set_device(int(os.environ.get("VFT_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(os.environ.get("VFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
+    elif world == 1 and os.environ.get("VFT_DP_ALWAYS_REDUCE", "0") == "1" and not dist.is_initialized():
+        # rehearsal hook (trainer/dp.py): a one-rank group, so that the gradient exchange really calls the backend
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(os.environ.get("VFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"), rank=0, world_size=1)
 
 
 class Trainer:

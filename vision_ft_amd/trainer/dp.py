@@ -16,6 +16,8 @@ links stay busy while the optimizer waits only for the last one.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -73,6 +75,12 @@ class DataParallelGrads:
         self.flat = FlatGradBuffer(list(params))
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # Does a step exchange gradients?  World > 1 — or, as a rehearsal hook, a ONE-rank process group with
+        # VFT_DP_ALWAYS_REDUCE=1: the whole N > 1 step (side stream, pre-scale, RCCL all-reduce, split graphs) then runs on a
+        # one-GPU box, RCCL included (its one-rank all-reduce is the identity), which is how tests/test_dp_gpu.py and
+        # `VFT_DP_ALWAYS_REDUCE=1 python bench.py` exercise the RCCL call path without a second GPU.
+        self.collective = self.world > 1 or (os.environ.get("VFT_DP_ALWAYS_REDUCE", "0") == "1" and dist.is_available()
+                                             and dist.is_initialized())
         self.bucket_bytes = bucket_bytes
         dev = self.flat.params[0].device if self.flat.params else torch.device("cpu")
         self.on_gpu = dev.type == "cuda"
@@ -81,7 +89,7 @@ class DataParallelGrads:
         self._pending = False
 
     def reduce_async(self) -> None:
-        if self.world == 1:
+        if not self.collective:
             return
         if self.on_gpu:
             ready = torch.cuda.Event()

@@ -100,7 +100,7 @@ class GraphedTrainStep:
         self.after_backward = after_backward
         self.loss_scale = float(loss_scale)  # 1 / gradient_accumulation_steps; the reported loss stays unscaled
         self.capturable = optimizer_is_capturable(optimizer)
-        self.single = dp.world == 1 and not split and self.capturable
+        self.single = not dp.collective and not split and self.capturable
         self.loss: torch.Tensor | None = None
         self._eager(warmup)  # allocator, MIOpen find, lazy kernel attributes: everything un-capturable happens here
         self._capture(pool, opt_graph)
