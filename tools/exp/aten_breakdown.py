@@ -58,7 +58,7 @@ def main():
     n = 0
     for e in kshape:
         t = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))
-        if not e.key.startswith("aten::") or t <= 0 or e.key in ("aten::mm", "aten::addmm"):
+        if not e.key.startswith("aten::") or t <= 0:
             continue
         print(f"{e.key:28s} n={e.count:5d} dev={t / 1000:8.2f} ms  {str(e.input_shapes)[:150]}")
         n += 1

@@ -58,7 +58,7 @@ class TimestepEmbedder(nn.Module):
 
     def forward(self, timesteps: torch.Tensor) -> torch.Tensor:
         emb = get_timestep_embedding(timesteps, self.time_embed_dim, flip_sin_to_cos=True, downscale_freq_shift=0)
-        return self.mlp(emb.to(module_dtype(self.mlp[0])))
+        return _seq(self.mlp, emb.to(module_dtype(self.mlp[0])))
 
 
 class Rope(NamedTuple):
@@ -69,6 +69,23 @@ class Rope(NamedTuple):
 
     def rows(self, sel) -> "Rope":
         return Rope(self.cos[sel], self.sin[sel])
+
+
+def _proj(layer: nn.Module, h: torch.Tensor) -> torch.Tensor:
+    """layer(h).  A plain frozen bf16 nn.Linear (the refiner blocks of a LoRA run: not adapted, not quantised) runs on the
+    projection GEMM of the adapted layers (kernels.linear) instead of the library's: at these sizes hipBLASLt picks stream-K
+    solutions whose partial sums meet through atomics — the only launches of a Lumina2 step that were not run-to-run
+    reproducible.  LoRA / NF4 wrappers and trainable layers keep their own forward."""
+    if type(layer) is nn.Linear and h.is_cuda and kernels.linear_eligible(h, layer.weight):
+        return kernels.linear(h, layer.weight, layer.bias)
+    return layer(h)
+
+
+def _seq(seq: nn.Sequential, h: torch.Tensor) -> torch.Tensor:
+    """nn.Sequential.forward with its Linear members through `_proj` (the conditioning MLPs: SiLU -> Linear, Linear -> SiLU -> Linear)."""
+    for m in seq:
+        h = _proj(m, h)
+    return h
 
 
 class SelfAttention(nn.Module):
@@ -94,7 +111,7 @@ class SelfAttention(nn.Module):
     def forward(self, hidden_states: torch.Tensor, freqs_cis: Rope, mask: torch.Tensor | None = None,
                 kv_len: torch.Tensor | None = None) -> torch.Tensor:
         b, s, _ = hidden_states.shape
-        qkv = self.qkv(hidden_states)
+        qkv = _proj(self.qkv, hidden_states)
         D = self.head_dim
         # strided views into the fused projection output: no split copies
         # (one autograd node for the three views: their gradients come back side by side in one pass)
@@ -109,7 +126,7 @@ class SelfAttention(nn.Module):
         k = kernels.qk_norm_rope(k, "rms", self.k_norm.weight, 1e-6, freqs_cis.cos, freqs_cis.sin)
         attn = scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask=mask,
                                             kv_len=kv_len, scale=math.sqrt(1 / D))
-        return self.out(attn.transpose(1, 2).flatten(-2))
+        return _proj(self.out, attn.transpose(1, 2).flatten(-2))
 
 
 class FeedForward(nn.Module):
@@ -127,8 +144,8 @@ class FeedForward(nn.Module):
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         pair = kernels.lora_siblings(hidden_states, (self.w1, self.w3)) if hidden_states.is_cuda else None  # chained data gradients
-        a, b = pair if pair is not None else (self.w1(hidden_states), self.w3(hidden_states))
-        return self.w2(kernels.swiglu(a, b))
+        a, b = pair if pair is not None else (_proj(self.w1, hidden_states), _proj(self.w3, hidden_states))
+        return _proj(self.w2, kernels.swiglu(a, b))
 
 
 class TransformerBlock(nn.Module):
@@ -170,7 +187,7 @@ class TransformerBlock(nn.Module):
         x = hidden_states
         if self.use_adaln:
             assert adaln_input is not None, "adaln_input must be provided for AdaLN"
-            sc_a, g_a, sc_m, g_m = self.adaLN_modulation(adaln_input).chunk(4, dim=1)
+            sc_a, g_a, sc_m, g_m = _seq(self.adaLN_modulation, adaln_input).chunk(4, dim=1)
             # the block input feeds norm1 and the gated add: the two gradients meet inside norm1's backward kernel
             n, x = self._norm_skip(self.attention_norm1, x, sc_a)
             a = self.attention(n, freqs_cis, mask=mask, kv_len=kv_len)
@@ -198,9 +215,9 @@ class FinalLayer(nn.Module):
         return tensor * (1 + scale.unsqueeze(1))
 
     def forward(self, hidden_states: torch.Tensor, adaln_input: torch.Tensor) -> torch.Tensor:
-        scale = self.adaLN_modulation(adaln_input)
+        scale = _seq(self.adaLN_modulation, adaln_input)
         zero = torch.zeros_like(scale)
-        return self.linear(kernels.layer_norm_modulate(hidden_states, zero, scale, self.norm_final.eps))
+        return _proj(self.linear, kernels.layer_norm_modulate(hidden_states, zero, scale, self.norm_final.eps))
 
 
 class RoPEEmbedder:
@@ -443,12 +460,12 @@ class NextDiT(nn.Module):
             oidx = (lenb + jn.unsqueeze(0) + boff).reshape(-1)
 
         t = self.t_embedder(timestep)
-        cap = self.cap_embedder[1](kernels.rms_norm_scale(caption_features.to(dtype), self.cap_embedder[0].weight, None,
+        cap = _proj(self.cap_embedder[1], kernels.rms_norm_scale(caption_features.to(dtype), self.cap_embedder[0].weight, None,
                                                           self.cap_embedder[0].eps))
         for layer in self.context_refiner:
             cap = self._run(layer, cap, cap_rope, None, None, ck)
         patches = latents.to(dtype).reshape(b, c, gh, p, gw, p).permute(0, 2, 4, 3, 5, 1).reshape(b, N, p * p * c)
-        x = self.x_embedder(patches)
+        x = _proj(self.x_embedder, patches)
         for layer in self.noise_refiner:
             x = self._run(layer, x, img_rope, t, None, ik)
         ctx = _TakeRows.apply(torch.cat([cap, x], dim=1).reshape(b * T, -1), gidx).view(b, T, -1)
@@ -497,14 +514,14 @@ class NextDiT(nn.Module):
         else:
             # prefix masks: the valid caption rows of sample i are rows [0, cap_lens[i])
             cap_in, _, _ = _pad_rows([caption_features[i][: cap_lens[i]] for i in range(b)], dev, want_mask=False)
-            cap = self.cap_embedder[1](kernels.rms_norm_scale(cap_in.to(dtype), self.cap_embedder[0].weight, None,
+            cap = _proj(self.cap_embedder[1], kernels.rms_norm_scale(cap_in.to(dtype), self.cap_embedder[0].weight, None,
                                                               self.cap_embedder[0].eps))
             for layer in self.context_refiner:
                 cap = self._run(layer, cap, lay["cap_rope"], None, None, lay["ck"])
 
         # noise refiner
         patches, _, _ = _pad_rows([self.patchify(im.to(dtype)) for im in images], dev, want_mask=False)
-        x = self.x_embedder(patches)
+        x = _proj(self.x_embedder, patches)
         for layer in self.noise_refiner:
             x = self._run(layer, x, lay["img_rope"], t, None, lay["ik"])
 
