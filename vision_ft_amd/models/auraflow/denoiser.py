@@ -69,7 +69,7 @@ class AuraMLP(nn.Module):
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         a, b = _project_all(hidden_states, (self.c_fc1, self.c_fc2))
         gated = kernels.swiglu(a, b) if self.hidden_act == "silu" else self.act(a) * b
-        return self.c_proj(gated)
+        return _proj(self.c_proj, gated)
 
 
 class MultiHeadLayerNorm(nn.Module):
@@ -86,11 +86,27 @@ class MultiHeadLayerNorm(nn.Module):
         return (self.weight.float() * h.float()).to(hidden_states.dtype)
 
 
+def _proj(layer: nn.Module, h: torch.Tensor) -> torch.Tensor:
+    """layer(h); a plain frozen bf16 nn.Linear (modulation / embedder projections a LoRA run does not adapt) runs on the own
+    projection GEMM (kernels.linear) instead of the library's: no stream-K / split-K launches with atomics left in the step,
+    and the same kernels eagerly and under graph capture.  Adapter / quantised wrappers and trainable layers keep their forward."""
+    if type(layer) is nn.Linear and h.is_cuda and kernels.linear_eligible(h, layer.weight):
+        return kernels.linear(h, layer.weight, layer.bias)
+    return layer(h)
+
+
+def _seq(seq: nn.Sequential, h: torch.Tensor) -> torch.Tensor:
+    """nn.Sequential.forward with its Linear members through `_proj` (activation -> Linear modulations, the timestep MLP)."""
+    for m in seq:
+        h = _proj(m, h)
+    return h
+
+
 def _project_all(x: torch.Tensor, layers) -> list[torch.Tensor]:
     """[layer(x) for layer in layers]; LoRA-wrapped siblings run as one autograd node whose data gradients are chained
     through the GEMM epilogue (kernels.lora_siblings) instead of being summed by separate elementwise passes."""
     outs = kernels.lora_siblings(x, layers) if x.is_cuda else None
-    return outs if outs is not None else [layer(x) for layer in layers]
+    return outs if outs is not None else [_proj(layer, x) for layer in layers]
 
 
 def _qk_norm(norm: nn.Module, x: torch.Tensor, rope: tuple[torch.Tensor, torch.Tensor] | None) -> torch.Tensor:
@@ -139,7 +155,7 @@ class SingleAttention(nn.Module):
         q = _qk_norm(self.q_norm1, pq.view(shape), rope)
         k = _qk_norm(self.k_norm1, pk.view(shape), rope)
         v = pv.view(shape)
-        return self.w1o(_attend(q, k, v, 1 / self.head_dim**0.5))
+        return _proj(self.w1o, _attend(q, k, v, 1 / self.head_dim**0.5))
 
 
 class DoubleAttention(nn.Module):
@@ -178,7 +194,7 @@ class DoubleAttention(nn.Module):
         v = torch.cat([v1.view(b, sc, H, D), v2.view(b, sl, H, D)], dim=1)
         out = _attend(q, k, v, None)
         c_out, l_out = out.split([sc, sl], dim=1)
-        return self.w1o(c_out), self.w2o(l_out)
+        return _proj(self.w1o, c_out), _proj(self.w2o, l_out)
 
 
 BLOCK_SKIPS = os.environ.get("VFT_BLOCK_SKIPS", "1") != "0"  # A/B switch
@@ -206,8 +222,8 @@ class MMDiTBlock(nn.Module):
         self.attn = DoubleAttention(dim, heads, use_flash_attn=use_flash_attn, use_rope=use_rope)
 
     def forward(self, condition, patches, global_cond, rope_freqs=None, **kwargs):
-        c_sh1, c_sc1, c_g1, c_sh2, c_sc2, c_g2 = self.modC(global_cond).chunk(6, dim=1)
-        x_sh1, x_sc1, x_g1, x_sh2, x_sc2, x_g2 = self.modX(global_cond).chunk(6, dim=1)
+        c_sh1, c_sc1, c_g1, c_sh2, c_sc2, c_g2 = _seq(self.modC, global_cond).chunk(6, dim=1)
+        x_sh1, x_sc1, x_g1, x_sh2, x_sc2, x_g2 = _seq(self.modX, global_cond).chunk(6, dim=1)
         eps = self.normC1.eps
         c_n1, c_skip1, c_skip2 = _norm_with_skips(condition, c_sh1, c_sc1, eps)
         x_n1, x_skip1, x_skip2 = _norm_with_skips(patches, x_sh1, x_sc1, eps)
@@ -233,7 +249,7 @@ class DiTBlock(nn.Module):
         self.mlp = AuraMLP(dim, hidden_dim=dim * 4)
 
     def forward(self, context, global_cond, rope_freqs=None, **kwargs):
-        sh1, sc1, g1, sh2, sc2, g2 = self.modCX(global_cond).chunk(6, dim=1)
+        sh1, sc1, g1, sh2, sc2, g2 = _seq(self.modCX, global_cond).chunk(6, dim=1)
         eps = self.norm1.eps
         # the block input feeds norm1 and BOTH gated adds: its three gradients meet inside norm1's backward kernel
         n1, skip1, skip2 = _norm_with_skips(context, sh1, sc1, eps)
@@ -266,7 +282,7 @@ class TimestepEmbedder(nn.Module):
 
     def forward(self, timestep: torch.Tensor) -> torch.Tensor:
         freq = self.timestep_embedding(timestep.float(), self.frequency_embedding_size)
-        return self.mlp(freq.to(module_dtype(self.mlp[0])))
+        return _seq(self.mlp, freq.to(module_dtype(self.mlp[0])))
 
 
 class MMDiT(nn.Module):
@@ -374,7 +390,7 @@ class MMDiT(nn.Module):
                 shortcut_duration: int | None = None, guidance_scale: float | None = None, **kwargs) -> torch.Tensor:
         b, _c, height, width = latent.shape
         dtype = module_dtype(self.init_x_linear)
-        cond = self.cond_seq_linear(encoder_hidden_states[:b].to(dtype))
+        cond = _proj(self.cond_seq_linear, encoder_hidden_states[:b].to(dtype))
         cond = torch.cat([self.register_tokens.expand(b, -1, -1).to(dtype), cond], dim=1)
 
         g = self.t_embedder(timestep)
@@ -385,7 +401,7 @@ class MMDiT(nn.Module):
             assert self.guidance_embedder is not None, "guidance_scale is provided but guidance_embedder is not set"
             g = g + self.guidance_embedder(timestep)
 
-        x = self.init_x_linear(self.patchify(latent.to(dtype)))
+        x = _proj(self.init_x_linear, self.patchify(latent.to(dtype)))
         if self.rope_frequency is not None:
             rope = self._rope_for(cond.size(1), height, width, latent.device)
         else:
@@ -408,8 +424,8 @@ class MMDiT(nn.Module):
                     ctx = layer(ctx, g, rope, **kwargs)
             x = ctx[:, n_cond:]
 
-        f_shift, f_scale = self.modF(g).chunk(2, dim=1)
-        x = self.final_linear(modulate(x, f_shift, f_scale))
+        f_shift, f_scale = _seq(self.modF, g).chunk(2, dim=1)
+        x = _proj(self.final_linear, modulate(x, f_shift, f_scale))
         return self.unpatchify(x, height // self.patch_size, width // self.patch_size)
 
 
