@@ -172,6 +172,44 @@ def gen_ops():
     print("ops:", len(T), "tensors")
 
 
+def gen_lora_conv():
+    """LoRAConv2d (src/modules/peft/lora.py:167-309): the reference layer's forward / backward on two geometries — a
+    3x3 / stride 1 / padding 1 convolution wide enough for the implicit-GEMM kernel (64 -> 96 channels) and a strided,
+    narrow one (8 -> 6, stride 2) — with a NON-zero up-projection so that every adapter gradient is exercised."""
+    from src.modules.peft.lora import LoRAConfig, LoRAConv2d
+
+    g = torch.Generator().manual_seed(77)
+    T = {}
+    for tag, (cin, cout, k, st, pd, hw, rank, alpha) in {"wide": (64, 96, 3, 1, 1, (12, 10), 4, 2.0),
+                                                         "strided": (8, 6, 3, 2, 1, (9, 14), 2, 1.0)}.items():
+        base = torch.nn.Conv2d(cin, cout, kernel_size=k, stride=st, padding=pd)
+        layer = LoRAConv2d(LoRAConfig(rank=rank, alpha=alpha), base)
+        sd = fw.synth_state_dict(shapes_of(layer), seed=5)
+        sd["alpha"] = torch.tensor(alpha)
+        cur = layer.state_dict()
+        layer.load_state_dict({k_: v.to(cur[k_].dtype) for k_, v in sd.items()}, strict=True)
+        layer.requires_grad_(True)
+        xin = torch.randn(2, cin, *hw, generator=g).requires_grad_(True)
+        with autocast():
+            y = layer(xin)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.to(y.dtype))
+        T[f"{tag}.x"], T[f"{tag}.y"], T[f"{tag}.gy"] = xin.detach(), y.detach().float(), gy
+        T[f"{tag}.dx"] = xin.grad
+        T[f"{tag}.d_down"] = layer.lora_down.weight.grad.float()
+        T[f"{tag}.d_up"] = layer.lora_up.weight.grad.float()
+        T[f"{tag}.geom"] = torch.tensor([cin, cout, k, st, pd, rank])
+        T[f"{tag}.alpha"] = torch.tensor(alpha)
+        layer.set_enabled(False)
+        with autocast(), torch.no_grad():
+            T[f"{tag}.y_disabled"] = layer(xin.detach()).float()
+        assert layer.lora_down.weight.dtype == torch.bfloat16 and base.weight.requires_grad is False
+    T["keys"] = torch.tensor(len(layer.state_dict()))
+    save_file(t2c(T), os.path.join(OUT, "lora_conv.safetensors"),
+              metadata={"state_dict_keys": json.dumps(sorted(layer.state_dict().keys()))})
+    print("lora_conv:", len(T), "tensors", sorted(layer.state_dict().keys()))
+
+
 # ----------------------------------------------------------------------------------------------
 TINY_SDXL = dict(in_channels=4, out_channels=4, hidden_dim=64, num_head_channels=64, context_dim=64,
                  block_out_channels=[64, 128, 128],  # global_cond_dim / additional_condition_dim are NOT
@@ -183,6 +221,12 @@ TINY_AURA = dict(in_channels=4, out_channels=4, patch_size=2, caption_projection
 TINY_LUMINA = dict(in_channels=8, out_channels=8, hidden_dim=256, caption_dim=48, timestep_embed_dim=64,
                    depth=2, num_heads=4, num_kv_heads=2, refiner_depth=1, multiple_of=64,
                    axes_dims=[16, 24, 24], axes_lens=[64, 32, 32], vae_channels=8)
+# The head geometries of the REAL models: AuraFlow's 256-wide heads over more than 512 tokens (the
+# stored-dS backward and attn_fwd2_kernel<256> only run there) and Lumina2's 96-wide heads with grouped K/V (6 query heads
+# on 2 key/value heads, as 24 / 8) and ragged caption lengths (the key-padding mask inside the head_dim 96 kernels).
+TINY_AURA_D256 = dict(TINY_AURA, caption_projection_dim=512, attention_head_dim=256, pos_embed_max_size=32 * 32)
+TINY_LUMINA_D96 = dict(TINY_LUMINA, hidden_dim=576, num_heads=6, num_kv_heads=2, axes_dims=[32, 32, 32],
+                       axes_lens=[64, 32, 32])
 
 
 def lora_train_steps(model, call, peft_include, rank, target_fn, steps=3):
@@ -367,21 +411,26 @@ def gen_sdxl_rope():
           "rope on/off output distance", float((T["out"] - T["out_rope_off"]).norm() / T["out_rope_off"].norm()))
 
 
-def gen_aura():
+def gen_aura(only=None):
     cfgm = importlib.import_module("src.models.auraflow.config")
     den = importlib.import_module("src.models.auraflow.denoiser")
     from src.modules.loss import flow_match as LF
 
-    for tag, extra in (("", {}), ("_rope", {"use_rope": True, "rope_dim_sizes": [16, 24, 24]})):
-        kw = dict(TINY_AURA, **extra)
+    for tag, base, extra, hw in (("", TINY_AURA, {}, (16, 24)),
+                                 ("_rope", TINY_AURA, {"use_rope": True, "rope_dim_sizes": [16, 24, 24]}, (16, 24)),
+                                 ("_d256", TINY_AURA_D256, {}, (48, 56)),  # 672 patches + 9 text + 8 registers = 689 tokens
+                                 ("_d256_rope", TINY_AURA_D256, {"use_rope": True, "rope_dim_sizes": [32, 112, 112]}, (48, 56))):
+        if only is not None and tag not in only:
+            continue
+        kw = dict(base, **extra)
         cfg = cfgm.DenoiserConfig(**kw)
         model = den.Denoiser(cfg)
         cs = load_synth(model, seed=1)
         g = torch.Generator().manual_seed(43)
         B = 2
         T = {
-            "latents": torch.randn(B, 4, 16, 24, generator=g),
-            "noise": torch.randn(B, 4, 16, 24, generator=g),
+            "latents": torch.randn(B, 4, *hw, generator=g),
+            "noise": torch.randn(B, 4, *hw, generator=g),
             "timestep": torch.tensor([0.3, 0.81]),
             "ehs": torch.randn(B, 9, 32, generator=g),
         }
@@ -406,7 +455,10 @@ def gen_aura():
         T["out"] = out.detach().float()
         T["loss"] = loss.detach().float()
         T["d_noisy"] = x.grad
+        big = "d256" in tag  # keep the wide fixtures small: the MLP / modulation weight gradients are 3-6 MB each there
         for name in ("final_linear.weight", "init_x_linear.weight", "double_layers.0.attn.w2q.weight",
+                     "single_layers.1.attn.w1k.weight", "register_tokens") if big else (
+                     "final_linear.weight", "init_x_linear.weight", "double_layers.0.attn.w2q.weight",
                      "single_layers.1.mlp.c_fc1.weight", "single_layers.0.modCX.1.weight", "register_tokens"):
             T["grad." + name] = dict(model.named_parameters())[name].grad
         model.zero_grad()
@@ -426,22 +478,23 @@ def gen_aura():
         print(f"aura{tag}: loss", float(T["loss"]), "lora losses", losses.tolist(), len(keys), "rank16", losses16.tolist())
 
 
-def gen_lumina():
+def gen_lumina(kw=None, fname="lumina_tiny.safetensors", hw=(16, 24), cap=(12, (12, 7))):
     cfgm = importlib.import_module("src.models.lumina2.config")
     den = importlib.import_module("src.models.lumina2.denoiser")
     from src.modules.loss import flow_match as LF
 
-    cfg = cfgm.DenoiserConfig(**TINY_LUMINA)
+    kw = TINY_LUMINA if kw is None else kw
+    cfg = cfgm.DenoiserConfig(**kw)
     model = den.Denoiser(cfg)
     cs = load_synth(model, seed=2)
     g = torch.Generator().manual_seed(44)
     B = 2
     T = {
-        "latents": torch.randn(B, 8, 16, 24, generator=g),
-        "noise": torch.randn(B, 8, 16, 24, generator=g),
+        "latents": torch.randn(B, 8, *hw, generator=g),
+        "noise": torch.randn(B, 8, *hw, generator=g),
         "timestep": torch.tensor([0.2, 0.77]),
-        "caption": torch.randn(B, 12, 48, generator=g),
-        "caption_mask": (torch.arange(12)[None, :] < torch.tensor([12, 7])[:, None]),
+        "caption": torch.randn(B, cap[0], 48, generator=g),
+        "caption_mask": (torch.arange(cap[0])[None, :] < torch.tensor(list(cap[1]))[:, None]),
     }
     t4 = (1 - T["timestep"]).view(B, 1, 1, 1)  # train/lumina2/text_to_image.py:109-121 inverts time
     T["noisy"] = (1 - t4) * T["latents"] + t4 * T["noise"]
@@ -464,11 +517,13 @@ def gen_lumina():
     for name in ("final_layer.linear.weight", "x_embedder.weight", "layers.0.attention.qkv.weight",
                  "layers.1.feed_forward.w2.weight", "noise_refiner.0.adaLN_modulation.1.bias",
                  "context_refiner.0.attention.q_norm.weight", "cap_embedder.1.weight"):
+        if kw is not TINY_LUMINA and "feed_forward" in name:
+            continue  # 3.5 MB at the wide geometry; the attention projections are what that fixture is for
         T["grad." + name] = dict(model.named_parameters())[name].grad
     model.zero_grad()
 
     # ragged batch: two different resolutions, list input (forward only)
-    rag = [torch.randn(8, 16, 24, generator=g), torch.randn(8, 8, 16, generator=g)]
+    rag = [torch.randn(8, *hw, generator=g), torch.randn(8, hw[0] // 2, hw[1] - 8, generator=g)]
     with autocast(), torch.no_grad():
         o2, _, capf = model(latents=rag, timestep=T["timestep"], caption_features=T["caption"],
                             caption_mask=T["caption_mask"])
@@ -480,9 +535,9 @@ def gen_lumina():
         model, call, ["attention", "feed_forward"], 4,
         lambda o: LF.loss_with_predicted_velocity(T["latents"], T["noise"], o))
     T["lora.losses"] = losses
-    meta = {"config": json.dumps(TINY_LUMINA), "checksum": repr(cs), "lora_keys": json.dumps(keys)}
-    save_file(t2c(T), os.path.join(OUT, "lumina_tiny.safetensors"), metadata=meta)
-    print("lumina: loss", float(T["loss"]), "lora losses", losses.tolist(), len(keys))
+    meta = {"config": json.dumps(kw), "checksum": repr(cs), "lora_keys": json.dumps(keys)}
+    save_file(t2c(T), os.path.join(OUT, fname), metadata=meta)
+    print(fname, "loss", float(T["loss"]), "lora losses", losses.tolist(), len(keys))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -797,8 +852,10 @@ def gen_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     import_reference()
-    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "sdxl_rope", "aura", "lumina", "samplers", "checkpoint_keys"]
+    which = sys.argv[1:] or ["ops", "index", "sdxl", "sdxl_rect", "sdxl_rope", "aura", "lumina", "lumina_d96", "lora_conv", "samplers", "checkpoint_keys"]
     torch.set_num_threads(8)
     for w in which:
-        {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "sdxl_rect": gen_sdxl_rect, "sdxl_rope": gen_sdxl_rope, "aura": gen_aura, "lumina": gen_lumina,
+        {"ops": gen_ops, "index": gen_index, "sdxl": gen_sdxl, "sdxl_rect": gen_sdxl_rect, "sdxl_rope": gen_sdxl_rope, "aura": gen_aura, "lumina": gen_lumina, "lora_conv": gen_lora_conv,
+         "aura_d256": lambda: gen_aura(only=("_d256", "_d256_rope")),
+         "lumina_d96": lambda: gen_lumina(TINY_LUMINA_D96, "lumina_tiny_d96.safetensors", hw=(32, 48), cap=(40, (40, 23))),
          "samplers": gen_samplers, "checkpoint_keys": gen_checkpoint_keys}[w]()

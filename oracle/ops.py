@@ -215,6 +215,14 @@ def linear(P: dict, name: str, x: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d(P: dict, name: str, x: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
+    if f"{name}.lora_down.weight" in P:
+        # LoRAConv2d, src/modules/peft/lora.py:167-309 (forward :245-258): down = the base convolution's kernel / stride /
+        # padding onto `rank` channels, up = 1x1, branch scaled by alpha / rank; base keys move under `<name>.conv2d.`
+        base = F.conv2d(x, P[f"{name}.conv2d.weight"], P.get(f"{name}.conv2d.bias"), stride=stride, padding=padding)
+        down = P[f"{name}.lora_down.weight"]
+        lo = F.conv2d(F.conv2d(x, down, None, stride=stride, padding=padding), P[f"{name}.lora_up.weight"],
+                      P.get(f"{name}.lora_up.bias"))
+        return base + lo * (P[f"{name}.alpha"] / down.shape[0])
     return F.conv2d(x, P[f"{name}.weight"], P.get(f"{name}.bias"), stride=stride, padding=padding)
 
 

@@ -102,6 +102,56 @@ def test_lora_matches_reference_golden(gpu):
     assert rel_err(B.grad.cpu(), G["lora.d_up"]) < 2e-2
 
 
+@pytest.mark.parametrize("tag", ["wide", "strided"])
+def test_lora_conv2d_matches_reference_golden(gpu, tag):
+    """LoRAConv2d on the GPU (reference src/modules/peft/lora.py:167-309) against the reference layer's own numbers and the
+    oracle's fp32 truth.  `wide` (64 -> 96, 3x3 / stride 1 / padding 1) runs its frozen base convolution on the implicit-GEMM
+    HIP kernel (forward and data gradient); `strided` (8 -> 6, stride 2) is a geometry that kernel does not take."""
+    from oracle import fixture_weights as fw
+    from oracle import ops
+    from oracle.attention import fp32_truth
+    from vision_ft_amd import kernels
+    from vision_ft_amd.modules.peft.lora import LoRAConfig, LoRAConv2d
+
+    G, _ = load_golden("lora_conv.safetensors")
+    cin, cout, k, st, pd, rank = (int(v) for v in G[f"{tag}.geom"])
+    sd = fw.synth_state_dict({"alpha": (), "conv2d.bias": (cout,), "conv2d.weight": (cout, cin, k, k),
+                              "lora_down.weight": (rank, cin, k, k), "lora_up.weight": (cout, rank, 1, 1)}, seed=5)
+    sd["alpha"] = G[f"{tag}.alpha"].clone()
+    sd = {k_: v.to(torch.bfloat16) for k_, v in sd.items()}  # the GPU module holds everything in bf16 (autocast's weight cast)
+    base = torch.nn.Conv2d(cin, cout, kernel_size=k, stride=st, padding=pd)
+    layer = LoRAConv2d(LoRAConfig(rank=rank, alpha=float(G[f"{tag}.alpha"])), base)
+    layer.load_state_dict(sd)
+    layer = layer.to(gpu, torch.bfloat16)
+    x = G[f"{tag}.x"].to(gpu, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert kernels.conv3x3_eligible(x, layer.conv2d.weight, (st, st), (pd, pd), (1, 1), 1) == (tag == "wide")
+    kernels.set_profiling(True)
+    y = layer(x)
+    y.backward(G[f"{tag}.gy"].to(gpu, torch.bfloat16))
+    torch.cuda.synchronize()
+    rep = kernels.profile_report()
+    kernels.set_profiling(False)
+    if tag == "wide":  # the base convolution really went through the HIP kernel, both directions
+        assert "conv3x3_fwd" in rep and "conv3x3_dgrad" in rep, sorted(rep)
+    # fp32 truth from the oracle on the same bf16-rounded operands
+    P = {f"c.{k_}": v.float() for k_, v in sd.items()}
+    for k_ in ("c.lora_down.weight", "c.lora_up.weight"):
+        P[k_] = P[k_].clone().requires_grad_(True)
+    xt = G[f"{tag}.x"].to(torch.bfloat16).float().requires_grad_(True)
+    with fp32_truth():
+        yt = ops.conv2d(P, "c", xt, stride=st, padding=pd)
+    yt.backward(G[f"{tag}.gy"].to(torch.bfloat16).float())
+    for name, got, ref, truth in (("y", y, G[f"{tag}.y"], yt), ("dx", x.grad, G[f"{tag}.dx"], xt.grad),
+                                  ("d_down", layer.lora_down.weight.grad, G[f"{tag}.d_down"], P["c.lora_down.weight"].grad),
+                                  ("d_up", layer.lora_up.weight.grad, G[f"{tag}.d_up"], P["c.lora_up.weight"].grad)):
+        e_gpu, e_ref = rel_err(got.float().cpu(), truth.detach()), rel_err(ref, truth.detach())
+        assert e_gpu < max(1e-2, 2 * e_ref), (tag, name, e_gpu, e_ref)  # as close to the truth as the reference's own bf16 run
+        assert rel_err(got.float().cpu(), ref) < 2e-2, (tag, name)
+    layer.set_enabled(False)
+    with torch.no_grad():
+        assert rel_err(layer(x.detach()).float().cpu(), G[f"{tag}.y_disabled"]) < 1e-2
+
+
 def test_lora_wgrad_deterministic(gpu):
     from vision_ft_amd import kernels
 

@@ -97,6 +97,73 @@ def test_lora_linear_matches_reference(G):
     assert torch.equal(P["l.lora_up.weight"].grad, G["lora.d_up"])
 
 
+def _lora_conv_case(tag):
+    from oracle import fixture_weights as fw
+
+    G, meta = load_golden("lora_conv.safetensors")
+    cin, cout, k, st, pd, rank = (int(v) for v in G[f"{tag}.geom"])
+    shapes = {"alpha": (), "conv2d.bias": (cout,), "conv2d.weight": (cout, cin, k, k),
+              "lora_down.weight": (rank, cin, k, k), "lora_up.weight": (cout, rank, 1, 1)}
+    assert sorted(shapes) == json.loads(meta["state_dict_keys"])  # the reference layer's own state-dict keys
+    sd = fw.synth_state_dict(shapes, seed=5)
+    sd["alpha"] = G[f"{tag}.alpha"].clone()
+    # the reference layer keeps the adapter in bf16 (LoRAConfig.dtype default) and the base convolution in fp32
+    sd = {k_: (v.to(torch.bfloat16) if k_.startswith("lora") or k_ == "alpha" else v) for k_, v in sd.items()}
+    return G, sd, (cin, cout, k, st, pd, rank)
+
+
+@pytest.mark.parametrize("tag", ["wide", "strided"])
+def test_lora_conv2d_oracle_matches_reference(tag):
+    """oracle/ops.py::conv2d's LoRAConv2d branch against the reference layer's own forward / backward numbers
+    (src/modules/peft/lora.py:167-309; tests/golden/lora_conv.safetensors, written by oracle/gen_golden.py::gen_lora_conv)."""
+    G, sd, (cin, cout, k, st, pd, rank) = _lora_conv_case(tag)
+    P = {f"c.{k_}": v for k_, v in sd.items()}
+    for k_ in ("c.lora_down.weight", "c.lora_up.weight"):
+        P[k_] = P[k_].clone().requires_grad_(True)
+    x = G[f"{tag}.x"].clone().requires_grad_(True)
+    with autocast_cpu():
+        y = ops.conv2d(P, "c", x, stride=st, padding=pd)
+    y.backward(G[f"{tag}.gy"].to(y.dtype))
+    assert torch.equal(y.float(), G[f"{tag}.y"])
+    assert torch.equal(x.grad, G[f"{tag}.dx"])
+    assert torch.equal(P["c.lora_down.weight"].grad.float(), G[f"{tag}.d_down"])
+    assert torch.equal(P["c.lora_up.weight"].grad.float(), G[f"{tag}.d_up"])
+
+
+@pytest.mark.parametrize("tag", ["wide", "strided"])
+def test_lora_conv2d_module_matches_reference_on_cpu(tag):
+    """The product's LoRAConv2d (vision_ft_amd/modules/peft/lora.py) — constructor, state-dict keys, frozen base, forward,
+    disabled forward, every adapter gradient, from_weights round trip — against the same golden numbers on the CPU."""
+    from vision_ft_amd.modules.peft.lora import LoRAConfig, LoRAConv2d
+
+    G, sd, (cin, cout, k, st, pd, rank) = _lora_conv_case(tag)
+    base = torch.nn.Conv2d(cin, cout, kernel_size=k, stride=st, padding=pd)
+    layer = LoRAConv2d(LoRAConfig(rank=rank, alpha=float(G[f"{tag}.alpha"])), base)
+    assert sorted(layer.state_dict()) == sorted(sd)
+    assert torch.count_nonzero(layer.lora_up.weight) == 0  # zero-init up: the adapter starts as a no-op (reference :235-238)
+    layer.load_state_dict(sd)
+    assert not base.weight.requires_grad and not base.bias.requires_grad and not layer.alpha.requires_grad
+    assert layer.lora_down.weight.requires_grad and layer.lora_up.weight.requires_grad
+    x = G[f"{tag}.x"].clone().requires_grad_(True)
+    with autocast_cpu():
+        y = layer(x)
+    y.backward(G[f"{tag}.gy"].to(y.dtype))
+    assert torch.equal(y.float(), G[f"{tag}.y"]) and torch.equal(x.grad, G[f"{tag}.dx"])
+    assert torch.equal(layer.lora_down.weight.grad.float(), G[f"{tag}.d_down"])
+    assert torch.equal(layer.lora_up.weight.grad.float(), G[f"{tag}.d_up"])
+    layer.set_enabled(False)
+    with autocast_cpu(), torch.no_grad():
+        assert torch.equal(layer(x.detach()).float(), G[f"{tag}.y_disabled"])
+    layer.set_enabled(True)
+    clone = LoRAConv2d.from_weights({k_: v for k_, v in layer.state_dict().items() if not k_.startswith("conv2d.")}, base)
+    with autocast_cpu(), torch.no_grad():
+        assert torch.equal(clone(x.detach()).float(), G[f"{tag}.y"])
+    layer.train()
+    assert not layer.conv2d.training
+    layer.requires_grad_(True)
+    assert not base.weight.requires_grad
+
+
 # ------------------------------------------------------------------------------------------
 # integer / string work: bit-exact
 # ------------------------------------------------------------------------------------------
@@ -275,7 +342,7 @@ def test_sdxl_rope_flow_match_oracle_matches_reference():
     torch.testing.assert_close(losses, T["lora.losses"], rtol=2e-3, atol=0)
 
 
-@pytest.mark.parametrize("tag", ["", "_rope"])
+@pytest.mark.parametrize("tag", ["", "_rope", "_d256", "_d256_rope"])
 def test_aura_oracle_matches_reference(tag):
     from vision_ft_amd.models.auraflow import Denoiser, DenoiserConfig
 
@@ -308,10 +375,11 @@ def test_aura_oracle_matches_reference(tag):
     torch.testing.assert_close(losses, T["lora16.losses"], rtol=2e-3, atol=0)
 
 
-def test_lumina_oracle_matches_reference():
+@pytest.mark.parametrize("fixture", ["lumina_tiny", "lumina_tiny_d96"])
+def test_lumina_oracle_matches_reference(fixture):
     from vision_ft_amd.models.lumina2 import Denoiser, DenoiserConfig
 
-    T, meta = load_golden("lumina_tiny.safetensors")
+    T, meta = load_golden(fixture + ".safetensors")
     cfgd = json.loads(meta["config"])
     with torch.device("meta"):
         mod = Denoiser(DenoiserConfig(**cfgd))

@@ -133,8 +133,11 @@ class LoRALinear(PeftLayer):
 
 class LoRAConv2d(PeftLayer):
     """Conv2d adapter: down = same kernel/stride/padding conv to `rank` channels, up = 1x1 conv
-    (reference :167-309).  Not targeted by any shipped config; kept for interface completeness and
-    executed with library convolutions."""
+    (reference :167-309).  Not targeted by any shipped config.  On the GPU the frozen BASE convolution runs the
+    implicit-GEMM HIP kernel whenever its geometry allows (3x3 / stride 1 / padding 1 or 1x1, channels % 32 == 0 —
+    `kernels.conv3x3` / `conv1x1`, forward and data gradient), whatever class the wrapped layer has; the rank-wide
+    branch (4-16 output channels: below the kernel's 32-channel granule) stays on the library convolutions.
+    Pinned by tests/golden/lora_conv.safetensors (reference-generated) on CPU and GPU."""
 
     adapter_param_names = ["lora_up", "lora_down", "alpha"]
     adapter_weight_names = ["lora_up.weight", "lora_up.bias", "lora_down.weight", "alpha"]
@@ -160,8 +163,17 @@ class LoRAConv2d(PeftLayer):
         nn.init.kaiming_uniform_(self.lora_down.weight)
         nn.init.zeros_(self.lora_up.weight)
 
+    def _base(self, x: torch.Tensor) -> torch.Tensor:
+        c = self.conv2d
+        if x.is_cuda and c.padding_mode == "zeros" and not isinstance(c.padding, str):
+            if kernels.conv3x3_eligible(x, c.weight, c.stride, c.padding, c.dilation, c.groups):
+                return kernels.conv3x3(x, c.weight, c.bias)
+            if kernels.conv1x1_eligible(x, c.weight, c.stride, c.padding, c.dilation, c.groups):
+                return kernels.conv1x1(x, c.weight, c.bias)
+        return c(x)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.conv2d(x)
+        y = self._base(x)
         if not self.enabled:
             return y
         return y + self.lora_up(self.lora_down(self.dropout(x))) * (self.alpha / self.rank)
