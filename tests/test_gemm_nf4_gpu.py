@@ -193,6 +193,65 @@ def test_nf4_dequant_once_equals_the_bf16_gemm_on_the_dequantised_weight_bitwise
     assert launches >= 2 * 4 * 2 * 2 and all(int(hdr[64 + 16 * c]) == (1024 * launches) % 2**32 for c in range(8)), hdr[:200:16]
 
 
+def test_nf4_barrier_timeout_is_loud(gpu, monkeypatch):
+    """VERDICT r4 weak #5 / ADVICE r4: a dequantising launch whose grid never meets (here: VFT_NF4_DEBUG=4 keeps workgroup 1
+    from arriving, what a workgroup held off the chip by a concurrent kernel looks like to the others; 8 = short spin limit)
+    must not compute on the incomplete weight image: every output element is NaN, the sticky error word is set,
+    `nf4_check_barrier()` — what the Trainer calls at its logging / checkpoint cadence — raises; after a reset the same
+    call gives the bits of a run that never failed."""
+    from vision_ft_amd import kernels
+
+    assert kernels.NF4_DEQUANT_ONCE
+    layer = _make_layer(gpu, 1280, 640, True, bias=False)[0]
+    q = layer.quant_state()
+    x = torch.randn(2048, 640, device=gpu).to(torch.bfloat16)
+    want = kernels._nf4_gemm(x, q, None, False)
+    want_t = kernels._nf4_gemm(want, q, None, True)
+    torch.cuda.synchronize()
+    assert not kernels.nf4_barrier_timed_out()
+    kernels.nf4_check_barrier()
+    monkeypatch.setenv("VFT_NF4_DEBUG", "12")
+    bad = kernels._nf4_gemm(x, q, None, False)
+    bad_t = kernels._nf4_gemm(want, q, None, True)
+    monkeypatch.delenv("VFT_NF4_DEBUG")
+    torch.cuda.synchronize()
+    assert torch.isnan(bad).all() and torch.isnan(bad_t).all()
+    assert kernels.nf4_barrier_timed_out()
+    with pytest.raises(RuntimeError, match="grid barrier"):
+        kernels.nf4_check_barrier()
+    kernels.nf4_reset_barrier()
+    assert not kernels.nf4_barrier_timed_out()
+    assert torch.equal(kernels._nf4_gemm(x, q, None, False), want) and torch.equal(kernels._nf4_gemm(want, q, None, True), want_t)
+    torch.cuda.synchronize()
+    assert not kernels.nf4_barrier_timed_out()
+
+
+def test_nf4_scratch_is_ordered_across_streams(gpu):
+    """one scratch (weight image + barrier words) per device — two NF4 GEMMs issued on different streams with no
+    dependency between them must still not overlap: the wrapper orders the second stream behind the first (event), so each
+    gives the bits of a serial run and no launch times out."""
+    from vision_ft_amd import kernels
+
+    la = _make_layer(gpu, 2304, 2304, True, bias=False)[0].quant_state()
+    lb = _make_layer(gpu, 1280, 640, False, bias=False)[0].quant_state()
+    xa = torch.randn(4096, 2304, device=gpu).to(torch.bfloat16)
+    xb = torch.randn(3000, 640, device=gpu).to(torch.bfloat16)
+    want_a, want_b = kernels._nf4_gemm(xa, la, None, False), kernels._nf4_gemm(xb, lb, None, False)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            ya = kernels._nf4_gemm(xa, la, None, False)
+        with torch.cuda.stream(s2):
+            yb = kernels._nf4_gemm(xb, lb, None, False)
+        outs.append((ya, yb))
+    torch.cuda.synchronize()
+    for ya, yb in outs:
+        assert torch.equal(ya, want_a) and torch.equal(yb, want_b)
+    assert not kernels.nf4_barrier_timed_out()
+
+
 def test_nf4_dequant_once_replays_from_a_graph(gpu):
     """Capturable: no host-side reset of the barrier words, static workspace address."""
     from vision_ft_amd import kernels

@@ -71,7 +71,14 @@ class Lumina2ForTextToImageTraining(DenoiserTask):
         # reference forward_and_loss :100-142: Lumina2 time runs 0 (noise) -> 1 (clean); prediction sign flipped
         t = self.sample_timesteps(latents.shape)
         noisy, noise = prepare_noised_latents(latents, (1 - t).to(latents.dtype))
-        if self.static_layout and cond.get("caption_lengths") is None and noisy.dim() == 4:
+        static_ok = self.static_layout and cond.get("caption_lengths") is None and noisy.dim() == 4
+        if not static_ok and noisy.is_cuda and torch.cuda.is_current_stream_capturing():
+            # `graph_safe` promises the shape-static forward; the ragged one reads lengths on the host (fails under capture) or,
+            # given host integers, would bake THIS batch's lengths and layout into the graph and replay them for every later
+            # batch.  A producer that hands over `caption_lengths` or a list of latents has to run eagerly.
+            raise RuntimeError("Lumina2 step captured into a HIP graph needs the static layout: stacked (B,C,H,W) latents and no "
+                               "`caption_lengths` in the conditions (set trainer.hip_graph: false for ragged batches)")
+        if static_ok:
             out, _, _ = self.model(latents=noisy, timestep=t, caption_features=cond["caption"], caption_mask=cond["mask"],
                                    static_layout=True)
         else:

@@ -2045,8 +2045,9 @@ class _AddChannelBias(torch.autograd.Function):
 
 
 def add_channel_bias(h: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """h + v[..., None, None] with the gradient of v reduced by vft_colsum (see _AddChannelBias)."""
-    if not (h.is_cuda and v.requires_grad and torch.is_grad_enabled()):
+    """h + v[..., None, None] with the gradient of v reduced by vft_colsum (see _AddChannelBias).  bf16 activations only (the
+    trainers' dtype): any other dtype keeps ATen's broadcast add and type promotion, as the reference computes it."""
+    if not (h.is_cuda and v.requires_grad and torch.is_grad_enabled() and h.dtype == torch.bfloat16):
         return h + (v.view(v.shape[0], v.shape[1], 1, 1) if v.dim() == 2 else v.view(1, -1, 1, 1))
     return _AddChannelBias.apply(h, v)
 
@@ -2187,23 +2188,70 @@ def _nf4_gemm_v1(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool) -> torc
 # dequantised inside the K-loop by every row tile.  Either way the 4-bit codes are the only copy that persists in HBM.
 NF4_DEQUANT_ONCE = os.environ.get("VFT_NF4_INLOOP", "0") == "0"
 _NF4_WS: dict = {}  # device -> list of workspaces ever handed out (never freed: captured graphs keep their addresses)
+_NF4_LAST_STREAM: dict = {}  # device -> the stream the scratch was last used on (eager launches and graph replays)
 
 
 def _nf4_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """One scratch per device, shared by every NF4 layer (launches on a stream are ordered, and a launch is done with the
-    scratch when it ends).  NOT for two streams at once: the trainers launch the step on one stream; keyed by device and not
-    by stream on purpose — the eager warm-up (side stream) creates and zeroes it, so that the capture that follows finds it
-    and records no 32 MB fill into the graph.  Its first 16 KiB hold the grid barrier's words (launch counter, arrival words,
-    error flag): zero at first use.  Grows by allocating a NEW buffer (the old one stays alive for graphs captured with it)."""
+    """One scratch per device, shared by every NF4 layer: it holds the transient bf16 image of ONE weight and, in its first
+    16 KiB, the grid barrier's words (launch counter, arrival words, sticky error flag; zero at first use).  Launches on one
+    stream are ordered and a launch is done with the scratch when it ends; a launch that arrives on ANOTHER stream is made
+    to wait for everything the previous stream has queued (`_nf4_order_streams`: an event recorded there, waited for here),
+    so two NF4 GEMMs of one device never overlap whatever streams their callers use (validation / sampling on a
+    side stream, a user-attached encoder, a changed DP schedule).  Keyed by device and not by stream on purpose — the eager
+    warm-up (side stream) creates and zeroes it, so the capture that follows finds it and records no 32 MB fill into the
+    graph; inside a capture the graph's own edges order the launches (torch.cuda.graph() synchronises the device on entry),
+    and a replay is announced by `nf4_note_replay`.  Grows by allocating a NEW buffer (the old one stays alive for graphs
+    captured with it)."""
     pool = _NF4_WS.setdefault(device, [])
     if not pool or pool[-1].numel() < nbytes:
         pool.append(torch.zeros(max(nbytes, 32 << 20), dtype=torch.uint8, device=device))
     return pool[-1]
 
 
+def _nf4_order_streams(device: torch.device) -> None:
+    if torch.cuda.is_current_stream_capturing():
+        return
+    cur = torch.cuda.current_stream(device)
+    last = _NF4_LAST_STREAM.get(device)
+    if last is not None and last != cur:
+        ev = torch.cuda.Event()
+        ev.record(last)  # behind everything `last` has queued so far, its NF4 launches included
+        cur.wait_event(ev)
+    _NF4_LAST_STREAM[device] = cur
+
+
+def nf4_note_replay(device: torch.device | None = None) -> None:
+    """Call right before replaying a captured graph that may contain NF4 launches (GraphedTrainStep does): the replaying
+    stream takes the scratch over from whatever stream used it last, with the same event dependency as an eager launch."""
+    if _NF4_WS:
+        for dev in ([device] if device is not None else list(_NF4_WS)):
+            _nf4_order_streams(dev)
+
+
 def nf4_barrier_timed_out() -> bool:
-    """True if a dequantising launch ever gave up waiting at its grid barrier (tests: the error word of every scratch)."""
+    """True if a dequantising launch ever gave up waiting at its grid barrier (the sticky error word of every scratch; a
+    host read = a synchronisation: call it where the host reads the loss anyway).  Such a launch wrote NaN to its output
+    instead of computing on the incomplete weight image."""
     return any(int(ws[:16].view(torch.int32)[2]) != 0 for pool in _NF4_WS.values() for ws in pool)
+
+
+def nf4_check_barrier() -> None:
+    """Raise if `nf4_barrier_timed_out()`: the trainers call this at their logging / checkpoint cadence."""
+    if _NF4_WS and nf4_barrier_timed_out():
+        raise RuntimeError(
+            "vft_linear_nf4: a dequantising launch timed out at its grid barrier (part of its persistent grid was kept off "
+            "the chip — a concurrent kernel on another stream or process, or a CU mask); its outputs were written as NaN. "
+            "Set VFT_NF4_INLOOP=1 (in-loop dequantisation, no grid barrier) or remove the concurrent work.")
+
+
+def nf4_reset_barrier() -> None:
+    """Zero the barrier words of every scratch (tests that provoke a time-out: the arrival counts of that launch are
+    incomplete for good).  Synchronises."""
+    torch.cuda.synchronize()
+    for pool in _NF4_WS.values():
+        for ws in pool:
+            ws[:16384].zero_()
+    torch.cuda.synchronize()
 
 
 def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None, ext_w=None, residual=None) -> torch.Tensor:
@@ -2219,6 +2267,7 @@ def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None
     if NF4_DEQUANT_ONCE:
         ws_bytes = int(_C.lib().vft_linear_nf4_workspace(q.out_features, q.in_features))
         ws = _nf4_workspace(a2.device, ws_bytes)
+        _nf4_order_streams(a2.device)
     with torch.cuda.device(a2.device), _Timed("gemm_nf4", 2.0 * M * N * (K + r)):
         st = _C.lib().vft_linear_nf4(_ptr(a2), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ext_x), _ptr(ext_w), _ptr(q.packed),
                                      _ptr(q.absmax_f32()), _ptr(q.code), q.out_features, q.in_features, M, r, a2.stride(0),

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .. import kernels
 from ..config import DEBUG_MODE_TYPE, TrainConfig
 from ..dataloader import get_dataloader_for_bucketing
 from ..dataset.util import DatasetConfig
@@ -216,6 +217,7 @@ class Trainer:
         if not self.saving_strategy.should_save(epoch, steps):
             return
         self.accelerator.wait_for_everyone()
+        kernels.nf4_check_barrier()  # never checkpoint weights trained through a timed-out NF4 launch
         if self.saving_callbacks and self.accelerator.is_main_process:
             sd, meta = self.raw_model.get_state_dict_to_save(), self.raw_model.get_metadata_to_save()
             for cb in self.saving_callbacks:
@@ -259,6 +261,7 @@ class Trainer:
                     loss = graphs[key](boundary)
                     if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
                         self.losses.append(float(loss.detach()))
+                        kernels.nf4_check_barrier()  # the host has just synchronised for the loss: read the NF4 error word too
                     nxt = next(it, None)
                     staged = nxt is not None and self.debug_mode != "1step"
                     if staged:
@@ -271,6 +274,7 @@ class Trainer:
                     self.backward(loss, step)
                     if step % self.raw_model.log_every == 0 or self.debug_mode == "1step":
                         self.losses.append(float(loss.detach()))
+                        kernels.nf4_check_barrier()
                     nxt = next(it, None)
                     self.apply_gradients(step)
                 self.call_saving_callbacks(epoch, step)

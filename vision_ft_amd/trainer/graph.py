@@ -18,6 +18,7 @@ from typing import Callable
 
 import torch
 
+from .. import kernels as _kernels
 from .dp import DataParallelGrads
 
 
@@ -136,15 +137,15 @@ class GraphedTrainStep:
         gc.collect()
         torch.cuda.empty_cache()
         self.graph_a = torch.cuda.CUDAGraph()
-        # the reported loss lives in its own one-element buffer OUTSIDE the graph's pool and is copied there right behind the
-        # forward pass: F.mse_loss returns a 0-dim tensor that owns the whole elementwise buffer (6 MB at the bench size),
-        # and round 4 found element 0 of that buffer — "the loss" — overwritten by the time a replay ends once the process
-        # had called torch.cuda.synchronize() (bench.py printed negative MSE values since round 2; training was not affected:
-        # the backward pass never reads the value)
-        static_loss = None
+        # The reported loss lives in its own one-element buffer allocated BEFORE the capture (default pool, never recycled
+        # by the graph's private pool) and is copied there right behind the forward pass: F.mse_loss used to return a 0-dim
+        # tensor that owns the whole elementwise buffer (6 MB at the bench size), and round 4 found element 0 of that
+        # buffer — "the loss" — overwritten by the time a replay ends once the process had called torch.cuda.synchronize()
+        # (the reduction itself is our own kernel since then).
+        static_loss = torch.zeros((), dtype=torch.float32, device=next(iter(self.dp.flat.buffers.values())).device)
         with torch.cuda.graph(self.graph_a, pool=pool):
             loss = self.forward_loss()
-            static_loss = loss.detach().clone()
+            static_loss.copy_(loss.detach())
             (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
             if self.single:
                 if self.after_backward is not None:
@@ -172,6 +173,7 @@ class GraphedTrainStep:
     def __call__(self, boundary: bool = True) -> torch.Tensor:
         """One micro-step (forward + backward); on an accumulation boundary also the gradient exchange and the
         optimizer step.  Returns the (device-resident, static) loss tensor of this micro-step."""
+        _kernels.nf4_note_replay()  # the replaying stream takes over the per-device NF4 scratch (no-op without NF4 layers)
         self.graph_a.replay()
         if self.graph_b is None:
             return self.loss
