@@ -111,8 +111,8 @@ def test_shard_indices_equal_counts_with_wraparound(n, world):
         assert [b[0] for b in bs] == shards[r], (r, [b[0] for b in bs], shards[r])
 
 
-def _toy_trainer(clip):
-    """Trainer over a CPU toy task: 3 bucket batches for 2 ranks (does not divide), gradient clipping on."""
+def _toy_trainer(clip, n_batches: int = 3):
+    """Trainer over a CPU toy task: `n_batches` bucket batches (3 for 2 ranks, 11 for 8: neither divides), clipping on."""
     import torch.utils.data as data
 
     from vision_ft_amd.config import TrainConfig
@@ -126,7 +126,7 @@ def _toy_trainer(clip):
 
     class ToyDataset(data.Dataset):
         def __len__(self):
-            return 3
+            return n_batches
 
         def __getitem__(self, i):
             g = torch.Generator().manual_seed(1000 + i)
@@ -162,11 +162,12 @@ def _toy_trainer(clip):
     return tr
 
 
-def _trainer_worker(rank: int, world: int, port: int, out):
+def _trainer_worker(rank: int, world: int, port: int, out, n_batches: int = 3):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        tr = _toy_trainer(clip=0.5)
+        tr = _toy_trainer(clip=0.5, n_batches=n_batches)
         tr.train()
         flat = torch.cat([p.detach().flatten() for p in tr.raw_model.model.parameters()])
         out[rank] = (flat, list(tr.raw_model.seen), len(tr.train_dataloader), len(tr.losses))
@@ -224,3 +225,42 @@ def _unclipped_reference():
                 (torch.nn.functional.mse_loss(model(b["x"]), b["y"]) / 2).backward()
             opt.step()
     return torch.cat([p.detach().flatten() for p in model.parameters()])
+
+
+def test_trainer_eight_ranks_uneven_batches():
+    """The driver's first real N = 8 run is the round-end scaling bench: rehearse the Trainer loop at world size 8 over gloo
+    with a batch count 8 does not divide (11 -> two steps per rank and epoch, the second round wraps to batches 0..4).  Every
+    rank must take the same number of steps (no rank left alone in an all-reduce), the replicas must stay bit-identical, and the
+    weights must equal a one-process run that averages the eight ranks' gradients, clips once and steps
+    (reference: src/trainer/common.py:287-365 under accelerate's DDP + even_batches sharding)."""
+    from vision_ft_amd.trainer.dp import shard_indices
+
+    world, n = 8, 11
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_trainer_worker, args=(world, port, out, n), nprocs=world, join=True)
+    shards = [shard_indices(n, r, world) for r in range(world)]
+    assert all(len(s) == 2 for s in shards)
+    for r in range(world):
+        flat, seen, nloader, nloss = out[r]
+        assert nloader == 2 and nloss == 4 and seen == shards[r] * 2, (r, seen)
+        assert torch.equal(flat, out[0][0])
+    tr = _toy_trainer(clip=0.5, n_batches=n)
+    tr.before_train()
+    model = tr.raw_model.model
+    ds = tr.dataset_config.get_dataset()
+    params = list(model.parameters())
+    opt = torch.optim.SGD(params, lr=0.05)
+    for _epoch in range(2):
+        for k in range(2):
+            grads = [torch.zeros_like(p) for p in params]
+            for r in range(world):
+                b = ds[shards[r][k]]
+                for a, g in zip(grads, torch.autograd.grad(torch.nn.functional.mse_loss(model(b["x"]), b["y"]), params)):
+                    a += g / world
+            for p, g in zip(params, grads):
+                p.grad = g
+            torch.nn.utils.clip_grad_norm_(params, 0.5)
+            opt.step()
+    torch.testing.assert_close(out[0][0], torch.cat([p.detach().flatten() for p in params]), rtol=1e-5, atol=1e-6)
