@@ -297,6 +297,12 @@ int vft_linear_nf4(const void* x, void* y, const void* bias, const void* residua
  */
 int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void* bias, int B, int H, int W, int Cin,
                     int Cout, void* stream);
+/* The same at STRIDE 2 (padding 1): y[B,H/2,W/2,Cout] from x[B,H,W,Cin]; H, W even, Cin % 64 == 0, Cout % 8 == 0.
+ * Replaces the convolution of the SDXL Downsample (sdxl/denoiser.py:371-408: nn.Conv2d(C, C, 3, stride=2, padding=1)),
+ * which MIOpen ran with atomics.  Its data / weight gradients are stride-1 calls (vft_conv3x3_fwd on the flipped,
+ * transposed weight / vft_conv3x3_wgrad) over the output gradient spread onto the even pixels of a zero H x W image. */
+int vft_conv3x3_s2_fwd(const void* x, const void* w, void* y, const void* bias, int B, int H, int W, int Cin,
+                       int Cout, void* stream);
 
 /* ---- fused linear layer (bf16 weight) ----------------------------------------------------------
  * y[M,N] = x[M,K] . w[N,K]^T (+ bias[N]) (+ ext_x[M,r] . ext_w[N,r]^T) (+ residual[M,N])

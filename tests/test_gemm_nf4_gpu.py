@@ -545,6 +545,77 @@ def test_conv3x3_implicit_gemm(gpu, B, Cin, Cout, H, W, bias):
         assert rel_err(xg2.grad.cpu(), xr.grad) < 5e-3
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(2, 64, 128, 16, 24, True), (3, 320, 320, 32, 32, True), (1, 128, 64, 10, 6, False),
+                                                  (2, 640, 640, 64, 64, True)])
+def test_conv3x3_stride2_forward_and_gradients(gpu, B, Cin, Cout, H, W, bias):
+    """The SDXL Downsample (src/models/sdxl/denoiser.py:371-408: 3x3, stride 2, padding 1) on the implicit-GEMM kernel's
+    stride-2 gather, its data / weight / bias gradients on the stride-1 kernels over the zero-upsampled output gradient —
+    against an fp32 F.conv2d on the same bf16-rounded operands; twice, bit-identical (no atomics)."""
+    import torch.nn.functional as F
+
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(B * 1000 + Cin + H)
+    x = _bf(g, B, Cin, H, W)
+    w = _bf(g, Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5)
+    bvec = _bf(g, Cout, sc=0.3) if bias else None
+    gy = _bf(g, B, Cout, H // 2, W // 2)
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    br = bvec.float().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=2, padding=1)
+    yr.backward(gy.float())
+    outs = []
+    for _ in range(2):
+        xg = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wg = w.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        bg = bvec.to(gpu).requires_grad_(True) if bias else None
+        assert kernels.conv3x3_s2_eligible(xg, wg, (2, 2), (1, 1), (1, 1), 1)
+        y = kernels.conv3x3_s2(xg, wg, bg)
+        y.backward(gy.to(gpu))
+        outs.append((y.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone() if bias else None))
+    y, dx, dw, db = outs[0]
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_err(y.cpu(), yr) < 5e-3, rel_err(y.cpu(), yr)
+    assert rel_err(dx.cpu(), xr.grad) < 5e-3, rel_err(dx.cpu(), xr.grad)
+    assert rel_err(dw.cpu(), wr.grad) < 1e-2, rel_err(dw.cpu(), wr.grad)
+    if bias:
+        assert rel_err(db.cpu(), br.grad) < 1e-2
+    for a, b_ in zip(outs[0], outs[1]):
+        assert a is None or torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 4, 64, 16, 24), (2, 64, 4, 16, 24), (1, 4, 320, 32, 32), (1, 320, 4, 32, 32), (2, 8, 24, 8, 8)])
+def test_conv3x3_narrow_channels_forward_and_gradients(gpu, B, Cin, Cout, H, W):
+    """The 4-channel stem and head of the UNet (src/models/sdxl/denoiser.py:1114 and :1111-1115) on the implicit-GEMM kernel
+    with zero-padded channels: forward, data / weight / bias gradients against fp32 F.conv2d; reproducible bit for bit."""
+    import torch.nn.functional as F
+
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = _bf(g, B, Cin, H, W)
+    w = _bf(g, Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5)
+    bvec = _bf(g, Cout, sc=0.3)
+    gy = _bf(g, B, Cout, H, W)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), bvec.float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yr.backward(gy.float())
+    outs = []
+    for _ in range(2):
+        xg = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wg, bg = w.to(gpu).requires_grad_(True), bvec.to(gpu).requires_grad_(True)
+        assert kernels.conv3x3_narrow_eligible(xg, wg, (1, 1), (1, 1), (1, 1), 1)
+        y = kernels.conv3x3_narrow(xg, wg, bg)
+        y.backward(gy.to(gpu))
+        outs.append((y.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone()))
+    y, dx, dw, db = outs[0]
+    assert y.shape == yr.shape
+    assert rel_err(y.cpu(), yr) < 5e-3 and rel_err(dx.cpu(), xr.grad) < 5e-3
+    assert rel_err(dw.cpu(), wr.grad) < 1e-2 and rel_err(db.cpu(), br.grad) < 1e-2
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+
+
 def test_every_tile_variant_gives_the_same_bits(gpu):
     """vft_linear_variant 1 / 2 / 3 (tile sizes) and 11 / 12 / 13 (whole rounds on that tile + the remaining rows as a second
     launch on a smaller tile): the K order per output element does not depend on the tile, so the results are bit-identical —

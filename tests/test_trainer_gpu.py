@@ -237,8 +237,12 @@ def test_graph_replay_takes_the_same_steps_as_eager(gpu, tmp_path, accum):
     # head / stride-2 convolutions are MIOpen kernels with atomics), graph-vs-eager 6e-3 .. 7.4e-2.  The per-step losses above
     # are the sharp check (rtol 2e-3); this bound only separates noise from a wrong gradient scale or a skipped accumulation,
     # which give O(1).
+    # Round 5: the stem / head / stride-2 convolutions left MIOpen (kernels.conv3x3_narrow / conv3x3_s2: no atomics), so the
+    # whole SDXL step is made of fixed-order kernels: two eager runs take bit-identical steps.
     noise = dist(u0, u0b)
-    assert dist(u0, u1) < max(3 * noise, 0.12), (dist(u0, u1), noise)
+    print(f"[determinism] eager-vs-eager weight distance {noise:.3e}, losses equal: {l0 == l0b}; graph-vs-eager {dist(u0, u1):.3e}")
+    assert l0 == l0b and all(torch.equal(u0[k], u0b[k]) for k in u0), (noise, l0, l0b)
+    assert dist(u0, u1) < 0.12, (dist(u0, u1), noise)
 
 
 def test_lumina2_trainer_replays_from_a_graph(gpu, tmp_path):

@@ -83,6 +83,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_linear_nf4": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_int64] * 3 + [c_int, c_void_p, c_int64, c_void_p]),
     "vft_linear_nf4_workspace": (c_int64, [c_int, c_int]),
     "vft_conv3x3_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "vft_conv3x3_s2_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "vft_linear_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_int64] * 4 + [c_void_p]),
     "vft_linear_variant": (c_int, [c_int]),
     "vft_linear_tile_hint": (c_int, [c_int] * 5),

@@ -534,14 +534,14 @@ int pick_tile(int M, int N, int K, int conv) {
 }  // namespace
 
 // cfg 1..3: one launch on that tile; 11..13: whole rounds on tile cfg - 10, the remaining rows as a second launch
-static void launch_lin8_cfg(Lin8Params q, int cfg, bool conv, hipStream_t st) {
+static void launch_lin8_cfg(Lin8Params q, int cfg, int conv, hipStream_t st) {
     if (cfg >= 11) {
         const int main_cfg = cfg - 10;
         const int M1 = vft_lin8_split_rows(q.M, q.N, main_cfg);
         if (M1 > 0) {
             Lin8Params a = q, b = q;
             a.M = M1;
-            a.x_rows = b.x_rows = q.M;
+            a.x_rows = b.x_rows = q.x_rows > 0 ? q.x_rows : q.M;
             b.m_begin = M1;
             b.q_packed = nullptr;  // NF4: the first launch has dequantised the weight into the scratch; the tail reads it as bf16
             vft_lin8_launch(a, main_cfg, conv, st);
@@ -652,6 +652,32 @@ extern "C" int vft_conv3x3_fwd(const void* x, const void* w, void* y, const void
     else
         launch_linear<Cfg<256, 128, 4, 3, 4, false, true>>(p, (hipStream_t)stream);
     VFT_CHECK_LAUNCH("vft_conv3x3_fwd");
+    return 0;
+}
+
+// 3x3 convolution, STRIDE 2, padding 1, channels-last (the SDXL Downsample, src/models/sdxl/denoiser.py:371-408):
+//   y[b,oh,ow,:] = bias + Σ_{kh,kw} x[b,2oh+kh-1,2ow+kw-1,:] · w[:,kh,kw,:]ᵀ      H, W even; output H/2 x W/2
+// The same implicit GEMM as vft_conv3x3_fwd — M = B*(H/2)*(W/2) output pixels, the activation rows gathered from the
+// H x W input by the LDS-DMA source addresses — so the two stride-2 convolutions of the UNet leave MIOpen (whose kernels
+// for them accumulate with atomics: the last non-reproducible launches of the SDXL step).  Their data / weight gradients
+// run on vft_conv3x3_fwd / vft_conv3x3_wgrad over the zero-upsampled output gradient (kernels.py::_Conv3x3S2).
+extern "C" int vft_conv3x3_s2_fwd(const void* x, const void* w, void* y, const void* bias, int B, int H, int W, int Cin,
+                                  int Cout, void* stream) {
+    VFT_CHECK_ARG(x && w && y, "vft_conv3x3_s2_fwd: null pointer");
+    VFT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "vft_conv3x3_s2_fwd: non-positive dimension");
+    VFT_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "vft_conv3x3_s2_fwd: H=%d and W=%d must be even", H, W);
+    VFT_CHECK_ARG(Cin % 64 == 0 && Cout % 8 == 0, "vft_conv3x3_s2_fwd: needs Cin %% 64 == 0 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    VFT_CHECK_ARG((int64_t)B * H * W < (1LL << 31), "vft_conv3x3_s2_fwd: too many pixels");
+    VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "vft_conv3x3_s2_fwd: pointers must be 16-byte aligned");
+    VFT_CHECK_ARG(bias == nullptr || ((uintptr_t)bias & 7) == 0, "vft_conv3x3_s2_fwd: misaligned bias");
+    Lin8Params q{};
+    q.x = (const bf16_t*)x, q.w = (const bf16_t*)w, q.y = (bf16_t*)y, q.bias = (const bf16_t*)bias;
+    q.M = B * (H / 2) * (W / 2), q.N = Cout, q.K = 9 * Cin, q.r = 0, q.ldx = Cin, q.ldw = 9 * (int64_t)Cin, q.ldy = Cout, q.ldres = 0;
+    q.cH = H, q.cW = W, q.cC = Cin, q.cHo = H / 2, q.cWo = W / 2, q.x_rows = B * H * W;
+    VFT_CHECK_ARG(vft_lin8_fits(q, 2), "vft_conv3x3_s2_fwd: operands beyond the 2 GiB the buffer descriptors address");
+    // (tile: the plain one-launch choice; cfg 1 maps to the 256x128 instantiation inside vft_lin8_launch)
+    vft_lin8_launch(q, g_variant > 0 && g_variant <= 3 ? g_variant : vft_lin8_pick_plain(q.M, q.N, q.K), 2, (hipStream_t)stream);
+    VFT_CHECK_LAUNCH("vft_conv3x3_s2_fwd");
     return 0;
 }
 

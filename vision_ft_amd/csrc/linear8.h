@@ -20,6 +20,7 @@ struct Lin8Params {
     int m_begin;         // first row this launch covers (rows [m_begin, M)); 0 except for the tail launch of a split problem
     int64_t ldx, ldw, ldy, ldres;
     int cH, cW, cC;      // CONV: image height / width / input channels (K = 9 * cC, cC % 64 == 0)
+    int cHo, cWo;        // CONV, stride 2: the output grid (cH / 2 x cW / 2); M = B * cHo * cWo, x_rows = B * cH * cW
     int x_bytes, w_bytes;  // extents of x and w for the buffer descriptors (set by vft_lin8_launch; < 2^31)
     int nt_store;          // y is stored with the non-temporal hint (set by vft_lin8_launch: outputs above 16 MiB)
     // NF4 base weight (vft_linear_nf4 with a workspace): q_packed != null makes the launch DEQUANTISE the weight first — every
@@ -38,10 +39,10 @@ struct Lin8Params {
 };
 
 // true when the operands fit the 32-bit offsets of the buffer descriptors (otherwise: first-generation kernel)
-bool vft_lin8_fits(const Lin8Params& p, bool conv);
+bool vft_lin8_fits(const Lin8Params& p, int conv);  // conv: 0 = linear, 1 = 3x3 stride 1, 2 = 3x3 stride 2
 
 // cfg: 1 = 256x256 tile (128 KiB LDS), 2 = 256x128 (96 KiB), 3 = 128x128 (64 KiB, two workgroups per CU).  K % 64 == 0.
-void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st);
+void vft_lin8_launch(Lin8Params p, int cfg, int conv, hipStream_t st);
 // tile configuration (1-3, or 11-13 = split launch) with the least modelled time for an (M, N, K) problem on 256 CUs;
 // _plain: among the one-launch configurations 1-3 only (the tail of a split launch)
 int vft_lin8_pick(int M, int N, int K);

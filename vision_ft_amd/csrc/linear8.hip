@@ -69,9 +69,11 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int BM_, int BN_, int WAVES_M_, bool CONV_>
+template <int BM_, int BN_, int WAVES_M_, bool CONV_, int STRIDE_ = 1>
 struct C8 {
     static constexpr bool CONV = CONV_;
+    static constexpr int STRIDE = STRIDE_;  // CONV: 1 = output grid == input grid; 2 = stride-2 / padding-1 (the SDXL Downsample)
+    static_assert(STRIDE_ == 1 || (CONV_ && STRIDE_ == 2), "stride 2 is a convolution mode");
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = 8 / WAVES_M_;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     static constexpr int FX = WM / 32, FW = WN / 32;            // 16-wide fragments per sub-tile (half of the wave tile)
@@ -342,7 +344,20 @@ __global__ __launch_bounds__(NT, C::WPS) void lin8_kernel(Lin8Params p) {
                 const int pm = min(m0 + row, p.M - 1);
                 gx[hh][q] = (int)(((int64_t)pm * p.ldx + dch * 8) * 2);
                 vmask[hh][q] = 0;
-                if (C::CONV) {
+                if (C::CONV && C::STRIDE == 2) {
+                    // stride 2, padding 1 (src/models/sdxl/denoiser.py:371-408): output pixel (oh, ow) of the cHo x cWo grid sits on
+                    // input pixel (2 oh, 2 ow) of the cH x cW image; the nine taps are the same row shifts as at stride 1
+                    const int how = p.cHo * p.cWo, bimg = pm / how, rem = pm - bimg * how, oh = rem / p.cWo, ow = rem - oh * p.cWo;
+                    const int ih0 = 2 * oh, iw0 = 2 * ow;
+                    gx[hh][q] = (int)((((int64_t)(bimg * p.cH + ih0) * p.cW + iw0) * p.ldx + dch * 8) * 2);
+                    unsigned m = 0;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int ih = ih0 + tap / 3 - 1, iw = iw0 + tap % 3 - 1;
+                        if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW) m |= 1u << tap;
+                    }
+                    vmask[hh][q] = m;
+                } else if (C::CONV) {
                     const int rem = pm % (p.cH * p.cW), oh = rem / p.cW, ow = rem - oh * p.cW;
                     unsigned m = 0;
 #pragma unroll
@@ -714,18 +729,18 @@ void launch8(const Lin8Params& p, hipStream_t st) {
 }  // namespace
 
 // cfg: 1 = 256x256, 2 = 256x128, 3 = 128x128 (see linear8.h)
-static int64_t x_extent(const Lin8Params& p, bool conv) {
+static int64_t x_extent(const Lin8Params& p, int conv) {
     const int64_t rows = p.x_rows > 0 ? p.x_rows : p.M;
     return conv ? rows * p.ldx * 2 : ((rows - 1) * p.ldx + p.K) * 2;
 }
 static int64_t w_extent(const Lin8Params& p) { return ((int64_t)(p.N - 1) * p.ldw + p.K) * 2; }
 
-bool vft_lin8_fits(const Lin8Params& p, bool conv) {
+bool vft_lin8_fits(const Lin8Params& p, int conv) {
     const int64_t lim = (1LL << 31) - 4096;
     return p.K % 64 == 0 && x_extent(p, conv) < lim && w_extent(p) < lim;
 }
 
-void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
+void vft_lin8_launch(Lin8Params p, int cfg, int conv, hipStream_t st) {
     static const int64_t nt_bytes = [] {  // VFT_LIN8_NT_MB: A/B knob (outputs above this many MiB are stored non-temporally; -1: never)
         const char* e = getenv("VFT_LIN8_NT_MB");
         const int64_t mb = e ? atoll(e) : -2;
@@ -734,7 +749,10 @@ void vft_lin8_launch(Lin8Params p, int cfg, bool conv, hipStream_t st) {
     p.nt_store = (int64_t)(p.M - p.m_begin) * p.N * 2 > nt_bytes;
     p.x_bytes = (int)x_extent(p, conv);
     p.w_bytes = (int)w_extent(p);
-    if (conv) {
+    if (conv == 2) {  // stride-2 convolution (two launches per SDXL step: no 256x256 instantiation — the 256x128 / 128x128 ones have registers to spare)
+        if (cfg == 3) launch8<C8<128, 128, 2, true, 2>>(p, st);
+        else launch8<C8<256, 128, 4, true, 2>>(p, st);
+    } else if (conv) {
         if (cfg == 1) launch8<C8<256, 256, 2, true>>(p, st);
         else if (cfg == 2) launch8<C8<256, 128, 4, true>>(p, st);
         else launch8<C8<128, 128, 2, true>>(p, st);

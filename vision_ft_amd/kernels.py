@@ -700,7 +700,7 @@ PACK_STATS = {"pack_hit": 0, "pack_miss": 0, "grad_in_place": 0, "grad_returned"
 def _grad_target(p: torch.Tensor | None):
     """The tensor a weight gradient may be accumulated into directly: the parameter's existing dense bf16 `.grad` (the
     trainer points it into the flat gradient buffer).  None -> the gradient has to be returned to autograd."""
-    g = getattr(p, "grad", None) if p is not None else None
+    g = getattr(p, "grad", None) if (p is not None and p.is_leaf) else None  # (a non-leaf — a padded copy — has no .grad to add into)
     if g is None or g.dtype != torch.bfloat16 or not g.is_contiguous() or not g.is_cuda or g.shape != p.shape:
         return None
     return g
@@ -1903,6 +1903,99 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, db
 
 
+# ---- the convolutions that used to stay on MIOpen (round 5): narrow channels and stride 2 -----------------------------------
+# MIOpen ran the 4-channel stem / head and the two stride-2 Downsample convolutions of the SDXL UNet with kernels that
+# accumulate through atomics: the last launches of the SDXL step whose results changed from run to run.
+NATIVE_SMALL_CONVS = os.environ.get("VFT_NATIVE_SMALL_CONVS", "1") != "0"  # A/B switch (0: MIOpen, as in rounds 1-4)
+
+
+def conv3x3_narrow_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:
+    """A 3x3 / stride 1 / padding 1 convolution whose channel counts are below the implicit-GEMM kernel's granule (the SDXL
+    stem 4 -> 320 and head 320 -> 4, src/models/sdxl/denoiser.py:1114): runs the same kernel on zero-padded channels."""
+    return (NATIVE_SMALL_CONVS and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and (weight.shape[1] % 32 != 0 or weight.shape[0] % 32 != 0)
+            and x.shape[0] * x.shape[2] * x.shape[3] < 2**31)
+
+
+def conv3x3_narrow(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """conv3x3 on channels padded with zeros to multiples of 64 (input) / 64 (output), the surplus output channels dropped.
+    Pure composition: the pads and the slice are differentiable copies, so the data gradient, the weight gradient
+    (vft_conv3x3_wgrad on the padded operands, then sliced) and the bias gradient (vft_colsum) come from `_Conv3x3`.
+    Cost at the SDXL sizes: 16x the stem's / head's real flops = ~0.15 ms per launch, against 0.3-0.5 ms on MIOpen."""
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    ci, co = (-Cin) % 64, (-Cout) % 64
+    xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, ci)) if ci else x
+    wp = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, ci, 0, co)) if (ci or co) else weight
+    bp = torch.nn.functional.pad(bias, (0, co)) if (bias is not None and co) else bias
+    y = conv3x3(xp.contiguous(memory_format=torch.channels_last), wp, bp)
+    return y[:, :Cout] if co else y
+
+
+def conv3x3_s2_eligible(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:
+    """The SDXL Downsample: 3x3 / stride 2 / padding 1, even image, channels % 64 == 0 (src/models/sdxl/denoiser.py:371-408)."""
+    return (NATIVE_SMALL_CONVS and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < 2**31)
+
+
+class _Conv3x3S2(torch.autograd.Function):
+    """Forward: vft_conv3x3_s2_fwd (the implicit GEMM gathering every second pixel).  Backward: the output gradient is spread
+    onto the even pixels of a zero H x W image; on that image the data gradient is the stride-1 call on the flipped,
+    transposed weight and the weight gradient the stride-1 vft_conv3x3_wgrad (the zeros contribute nothing) — 4x the minimal
+    flops on two launches per step (+0.8 ms), no atomics anywhere."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = weight.contiguous(memory_format=torch.channels_last)
+        y = torch.empty((B, Cout, H // 2, W // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device), _Timed("conv3x3_fwd", 18.0 * B * (H // 2) * (W // 2) * Cin * Cout):
+            st = _C.lib().vft_conv3x3_s2_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(_bf16_or_none(bias)), B, H, W, Cin, Cout, _stream())
+        _C.check(st, "vft_conv3x3_s2_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dx = dw = db = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if need_x or need_w:
+            up = torch.zeros((B, Cout, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+            up[:, :, ::2, ::2] = dy
+            if need_x:
+                dx = _conv3x3_call(up, _dgrad_weight(weight), None, B, H, W, Cout, Cin, "conv3x3_dgrad")
+            if need_w:
+                g2 = _conv_grad_target(ctx.wparam)
+                with torch.cuda.device(dy.device):
+                    if g2 is not None and conv3x3_wgrad_eligible(B, H, W, Cin, Cout):
+                        conv3x3_wgrad(up, x, out=g2, accumulate=True)
+                    elif conv3x3_wgrad_eligible(B, H, W, Cin, Cout):
+                        dw = conv3x3_wgrad(up, x).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).to(weight.dtype)
+                    else:
+                        dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                                 [False, True, False])[1]
+        if need_b:
+            db = colsum(dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, Cout), ctx.bparam)
+        return dx, dw, db
+
+
+def conv3x3_s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """3x3 / stride 2 / padding 1 convolution of a (B,Cin,H,W) tensor, channels-last in and out."""
+    _ready(x, weight)
+    _require_gpu(x, weight, bias)
+    return _Conv3x3S2.apply(x, weight, bias)
+
+
 CONV_WGRAD_KERNEL = os.environ.get("VFT_CONV_WGRAD", "1") != "0"  # A/B switch
 
 
@@ -1913,7 +2006,7 @@ def conv3x3_wgrad_eligible(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
 
 def _conv_grad_target(weight: torch.Tensor | None):
     """[Cout, 9*Cin] view ([tap][Cin] rows) of a convolution weight's existing channels-last bf16 gradient, or None."""
-    g = getattr(weight, "grad", None) if weight is not None else None
+    g = getattr(weight, "grad", None) if (weight is not None and weight.is_leaf) else None
     if g is None or g.dtype != torch.bfloat16 or not g.is_cuda or g.dim() != 4 or g.shape != weight.shape:
         return None
     g2 = g.permute(0, 2, 3, 1)

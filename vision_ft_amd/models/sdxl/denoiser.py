@@ -253,15 +253,20 @@ class TransformerBlock(nn.Module):
 
 
 class _Conv2d(nn.Conv2d):
-    """nn.Conv2d parameters; 3x3 / stride 1 / padding 1 convolutions run the implicit-GEMM HIP kernel
-    (forward and data gradient), everything else (the 4-channel stem / head, stride-2 downsamples, 1x1 skips)
-    stays on MIOpen."""
+    """nn.Conv2d parameters; every convolution of the UNet runs the implicit-GEMM HIP kernel (forward, data and weight
+    gradient): 3x3 / stride 1 / padding 1 and 1x1 directly, the 4-channel stem / head on zero-padded channels, the
+    stride-2 Downsample through the kernel's stride-2 gather (round 5; MIOpen only for geometries none of these take)."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if kernels.conv3x3_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return kernels.conv3x3(x, self.weight, self.bias)
         if kernels.conv1x1_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return kernels.conv1x1(x, self.weight, self.bias)
+        if self.padding_mode == "zeros" and not isinstance(self.padding, str):
+            if kernels.conv3x3_narrow_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                return kernels.conv3x3_narrow(x, self.weight, self.bias)
+            if kernels.conv3x3_s2_eligible(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+                return kernels.conv3x3_s2(x, self.weight, self.bias)
         if self.bias is not None and self.bias.requires_grad and x.is_cuda and torch.is_grad_enabled() and self.padding_mode == "zeros":
             # a TRAINABLE bias of a convolution that stays on MIOpen (stem, head, stride-2): the convolution runs without it
             # and the bias is added by the op whose backward does not use ATen's long reduction (kernels.add_channel_bias)
