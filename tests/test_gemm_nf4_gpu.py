@@ -580,8 +580,11 @@ def test_conv3x3_stride2_forward_and_gradients(gpu, B, Cin, Cout, H, W, bias):
     assert rel_err(dw.cpu(), wr.grad) < 1e-2, rel_err(dw.cpu(), wr.grad)
     if bias:
         assert rel_err(db.cpu(), br.grad) < 1e-2
-    for a, b_ in zip(outs[0], outs[1]):
-        assert a is None or torch.equal(a, b_)
+    # bit-reproducible: output, data and bias gradient always; the weight gradient wherever vft_conv3x3_wgrad takes the shape
+    # (4 096 pixels and up — every SDXL bucket; below that the library's kernel, which sums with atomics, is the fallback)
+    for name, a, b_ in zip(("y", "dx", "dw", "db"), outs[0], outs[1]):
+        if a is not None and (name != "dw" or kernels.conv3x3_wgrad_eligible(B, H, W, Cin, Cout)):
+            assert torch.equal(a, b_), name
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 4, 64, 16, 24), (2, 64, 4, 16, 24), (1, 4, 320, 32, 32), (1, 320, 4, 32, 32), (2, 8, 24, 8, 8)])
@@ -612,8 +615,9 @@ def test_conv3x3_narrow_channels_forward_and_gradients(gpu, B, Cin, Cout, H, W):
     assert y.shape == yr.shape
     assert rel_err(y.cpu(), yr) < 5e-3 and rel_err(dx.cpu(), xr.grad) < 5e-3
     assert rel_err(dw.cpu(), wr.grad) < 1e-2 and rel_err(db.cpu(), br.grad) < 1e-2
-    for a, b_ in zip(outs[0], outs[1]):
-        assert torch.equal(a, b_)
+    for name, a, b_ in zip(("y", "dx", "dw", "db"), outs[0], outs[1]):
+        if name != "dw" or kernels.conv3x3_wgrad_eligible(B, H, W, (Cin + 63) // 64 * 64, (Cout + 63) // 64 * 64):
+            assert torch.equal(a, b_), name
 
 
 def test_every_tile_variant_gives_the_same_bits(gpu):

@@ -63,7 +63,8 @@ def main():
         for (B, Hq, Hkv, Sq, Sk, D) in shapes:
             unit = B * Hq * Sq * Sk * D / 1e9
             row = f"{name:7s} B{B} Hq{Hq} Hkv{Hkv} Sq{Sq} Sk{Sk} D{D}:"
-            for variant, (f, b_) in time_case(B, Hq, Hkv, Sq, Sk, D, (0, 3) if D != 96 else (0,), reps).items():
+            variants = tuple(int(v) for v in os.environ["VFT_AB_VARIANTS"].split(",")) if os.environ.get("VFT_AB_VARIANTS") else ((0, 3) if D != 96 else (0,))
+            for variant, (f, b_) in time_case(B, Hq, Hkv, Sq, Sk, D, variants, reps).items():
                 row += f"  [variant {variant}] fwd {f:7.3f} ms {4 * unit / f:7.1f} TF/s | bwd {b_:7.3f} ms {10 * unit / b_:7.1f} TF/s"
             print(row, flush=True)
 

@@ -2446,7 +2446,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
 // the Q / dO re-read per key block; at 256 keys per block that is ~2.4 + 1.2 TB/s beside an MFMA-bound loop.
 // Q / dO tiles arrive by LDS-DMA in a ring of three buffers; two workgroup barriers per tile.
 // =============================================================================================
-template <int D>
+// LEAN (round 5, the default): the per-tile bookkeeping on the scalar unit is incremental.  The ISA of the round-3/4 loop
+// carried 226 scalar and 213 vector instructions per 64-query tile and wave beside its 40 MFMAs — three integer divisions
+// (tile -> (query head, query tile) for the staging, the scratch plane and the final store), four buffer descriptors rebuilt
+// from 64-bit products, per-lane staging addresses and range checks recomputed per tile, a per-element key-mask select —
+// and at two waves per SIMD the kernel is bound by instruction ISSUE (~640 instructions x ~4.5 cycles per wave and tile
+// against 1 280 cycles of MFMA work), not by the matrix pipe, LDS or HBM.  Now: cursors advance by one tile, descriptors
+// are rebuilt only when the query head changes, the tensors' ends are the descriptors' ends (rows past them read zeros by
+// the hardware range check), the scratch plane of a (batch, kv head) pair is ONE descriptor indexed by the tile number, and
+// the key mask is applied only in a ragged key block.  LEAN = false keeps the old bookkeeping for A/B (vft_attn_variant(5)).
+template <int D, bool LEAN = true>
 __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     static_assert(D == 64, "the one-pass backward is built for head_dim 64 (register budget at two waves per SIMD)");
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, BQ = 64, QT = BQ / 32, KB = 256, NB = 3;
@@ -2485,9 +2494,45 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     const int64_t plane = (int64_t)p.B * p.Hq * nqt * (BQ * D);   // floats per scratch plane
     float* const scr = p.split_ws + (int64_t)split * plane;
 
+    // ---- LEAN staging state: the cursor (query head of the kv group, query tile) of the next tile to stage, the descriptors
+    //      of that head (Q, dO from the head's first row to its last; -lse/scale or -delta for waves 0 / 1, empty for the
+    //      others), and this lane's fixed part of the addresses (Stage: one 1 KiB piece per wave = rows 8 w .. 8 w + 7)
+    int sg = 0, stl = 0;
+    const int st_r = w * 8 + (lane >> 3);
+    const int st_c = ((lane & 7) ^ swz_f<RB>(st_r)) << 4;
+    int vq_lane = st_r * qs_s * 2 + st_c, vdo_lane = st_r * dos_s * 2 + st_c, vst_lane = lane * 4;
+    __amdgpu_buffer_rsrc_t hrq = __builtin_amdgcn_make_buffer_rsrc((void*)p.q, 0, 0, 0x00020000), hrdo = hrq, hrs = hrq;
+    auto head_rsrc = [&](int gq) {  // (gq >= G: past the last head — empty descriptors, every DMA of a dead tile reads zeros)
+        const bool livehead = gq < G;
+        const int hq = hkv * G + (livehead ? gq : 0);
+        hrq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + b * p.sq.b + hq * p.sq.h), 0, livehead ? (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2) : 0, 0x00020000);
+        hrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dout + b * p.sdo.b + hq * p.sdo.h), 0, livehead ? (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2) : 0, 0x00020000);
+        hrs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.nlse : p.delta) + ((int64_t)b * p.Hq + hq) * p.Sq), 0, (livehead && w < 2) ? p.Sq * 4 : 0, 0x00020000);
+    };
+    auto stage_lean = [&](int buf) {  // stages the tile under the cursor, then advances it
+        char* base = smem + buf * BUFB;
+        const int row0 = stl * BQ;
+        {
+            const int v0[1] = {vq_lane + row0 * qs_s * 2};
+            dma16_group<1>(hrq, base + w * 1024, v0);
+            const int v1[1] = {vdo_lane + row0 * dos_s * 2};
+            dma16_group<1>(hrdo, base + TILE + w * 1024, v1);
+        }
+        char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
+        dma4(hrs, sdst, vst_lane + row0 * 4);
+        if (++stl == nqt) {
+            stl = 0;
+            ++sg;
+            head_rsrc(sg);
+        }
+    };
     // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 64
     // -lse / scale values, wave 1 its -delta values (both prepared by attn_delta_kernel), the others a filler
     auto stage = [&](int it, int buf) {
+        if constexpr (LEAN) {
+            stage_lean(buf);
+            return;
+        }
         const bool live = it < niter;
         const int itc = live ? it : 0;
         const int gq = itc / nqt, t = itc % nqt;
@@ -2529,6 +2574,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         const int key = n0 + w * 32 + r;
         const bool kmem = key < p.Sk;   // memory-valid
         const bool kval = key < kvl;    // participates in the softmax
+        const bool ragged = n0 + KB > kvl;  // (block-uniform)
         // ---- the key block's operands: K / V fragments of this wave's 32 keys, the K image for the dQ product, the first
         //      two query tiles.  (Every wave has passed the last reads of the previous block: barrier at the loop's end.)
         bf16x8 Kf[KS], Vf[KS];
@@ -2543,6 +2589,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
             pin_loaded(Vf[ks]);
         }
         DmaTile<D, KB, 8>::issue(rk, smem + KIMG, n0, kvl, ks_s);
+        if constexpr (LEAN) {
+            sg = 0, stl = 0;
+            head_rsrc(0);
+        }
         stage(0, 0);
         stage(1, 1);
         f32x16 dK[DT], dV[DT];
@@ -2563,7 +2613,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         // The running dQ of tile `it` travels scratch plane -> LDS by DMA one tile ahead (no VGPR-destination load in the
         // loop: beside hidden DMAs the compiler would wait vmcnt(0) for it and drain the ring).  Nothing to read in the
         // range's first key block or past the last tile: an out-of-range offset delivers zeros.
+        // LEAN: the tiles of a (batch, kv head) pair are consecutive in the plane (tile id = first tile of the pair + it): one
+        // descriptor over the pair's niter tiles, the tile number times 16 KiB in the lane offset; past the last tile the
+        // offset is past the descriptor (zeros); in the range's first key block there is nothing to read (empty descriptor)
+        float* const pair_scr = scr + tile_id_of(0) * (BQ * D);
+        const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, first ? 0 : niter * (BQ * D * 4), 0x00020000);
+        const int old_lane = ((w & 3) * 1024 + (2 * kh) * 256 + lane * 4) * 4;
         auto old_dma = [&](int it) {
+            if constexpr (LEAN) {
+                const int voff = old_lane + it * (BQ * D * 4);
+                dma16_nt(rpl, smem + OLD + w * 2048, voff);
+                dma16_nt(rpl, smem + OLD + w * 2048 + 1024, voff + 1024);
+                return;
+            }
             const bool live = !first && it < niter;
             const float* tb = scr + tile_id_of(live ? it : 0) * (BQ * D);
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)tb, 0, BQ * D * 4, 0x00020000);
@@ -2576,6 +2638,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         __builtin_amdgcn_s_barrier();
 
         int buf = 0;
+        int cg = 0, ct = 0;  // LEAN: (query head of the kv group, query tile) of the tile being computed
         for (int it = 0; it < niter; ++it) {
             const char* Qs = smem + buf * BUFB;
             const char* dOs = Qs + TILE;
@@ -2638,9 +2701,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {  // V
                     float pv = __builtin_amdgcn_exp2f(S[i] * sc);
-                    if (!kval) pv = 0.f;
+                    if constexpr (!LEAN) {
+                        if (!kval) pv = 0.f;
+                    }
                     S[i] = pv;
                     dP[i] = pv * dP[i];
+                }
+                if constexpr (LEAN) {
+                    if (ragged) {  // block-uniform: only the last key block of a masked / non-multiple key range has keys to drop
+                        asm volatile("; ragged key block" ::: "memory");  // (keeps hipcc from if-converting the branch back into 64 selects per tile)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            S[i] = kval ? S[i] : 0.f;
+                            dP[i] = kval ? dP[i] : 0.f;
+                        }
+                    }
                 }
                 bf16x8 Pf[2], dSf[2];
                 Pf[0] = pack8(S, 0);
@@ -2720,7 +2795,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 sum0 = f32x4{acc[8], acc[9], acc[10], acc[11]} + p0 + o0;
                 sum1 = f32x4{acc[12], acc[13], acc[14], acc[15]} + p1 + o1;
             }
-            const int gq = it / nqt, t = it % nqt;
+            int gq, t;
+            if constexpr (LEAN) {
+                gq = cg, t = ct;
+                if (++ct == nqt) ct = 0, ++cg;
+            } else {
+                gq = it / nqt, t = it % nqt;
+            }
             if (final_store) {
                 const int q = t * BQ + qtw * 32 + r;
                 if (q < p.Sq) {
@@ -2729,6 +2810,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                     store4(dst, sum0[0] * s_, sum0[1] * s_, sum0[2] * s_, sum0[3] * s_);
                     store4(dst + 8, sum1[0] * s_, sum1[1] * s_, sum1[2] * s_, sum1[3] * s_);
                 }
+            } else if constexpr (LEAN) {
+                float* s0 = pair_scr + (int64_t)it * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
+                *reinterpret_cast<f32x4*>(s0) = sum0;
+                *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
             } else {
                 float* s0 = scr_ptr(it);
                 *reinterpret_cast<f32x4*>(s0) = sum0;
@@ -2869,7 +2954,7 @@ __host__ inline int dkdv_nsplit(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
 // slice; the chip holds 256 workgroups: fewest rounds x passes wins, ties go to fewer slices (no reduce pass at 1).
 __host__ inline int bwd1_slices(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     (void)Hq, (void)Sq;
-    if (D != 64 || Sk <= 128 || g_attn_variant != 0) return 0;
+    if (D != 64 || Sk <= 128 || (g_attn_variant != 0 && g_attn_variant != 5)) return 0;
     const int64_t bhk = (int64_t)B * Hkv, nkb = (Sk + 255) / 256;
     // time ~ rounds of the 256 resident workgroups x key-block passes per workgroup.  Slicing (ns > 1) costs one fp32 plane
     // per slice and a reduce pass over all of them (measured: 16 planes of 252 MB = 0.7 ms beside a 3 ms kernel), so it
@@ -2897,13 +2982,17 @@ int launch_bwd1(AttnParams p, hipStream_t st) {
     constexpr size_t lds = 3 * (2 * 64 * D * 2 + 512) + 256 * D * 2 + 256 * 128 + 8 * 2048 + 8 * 256 + 8 * 2048;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int64_t rows = (int64_t)p.B * p.Hq * p.Sq * (D / 8);
     hipLaunchKernelGGL(attn_delta_kernel<D>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
     VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
-    hipLaunchKernelGGL(attn_bwd1_kernel<D>, dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
+    if (g_attn_variant == 5)  // A/B: the round-3/4 per-tile bookkeeping
+        hipLaunchKernelGGL((attn_bwd1_kernel<D, false>), dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
+    else
+        hipLaunchKernelGGL((attn_bwd1_kernel<D, true>), dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
     VFT_CHECK_LAUNCH("vft_attn_bwd(one pass)");
     if (p.nsplit > 1) {
         const int64_t n = bwd1_plane_floats(p.B, p.Hq, p.Sq, D) / 4;
@@ -3149,7 +3238,7 @@ extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 extern "C" int vft_attn_variant(int variant) {
-    VFT_CHECK_ARG(variant >= 0 && variant <= 3, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels), 2 (8-wave dK/dV) or 3 (dq + dkdv pair where the one-pass backward would run)", variant);
+    VFT_CHECK_ARG((variant >= 0 && variant <= 3) || variant == 5, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels), 2 (8-wave dK/dV), 3 (dq + dkdv pair where the one-pass backward would run) or 5 (one-pass backward with the round-4 bookkeeping)", variant);
     g_attn_variant = variant;
     return 0;
 }

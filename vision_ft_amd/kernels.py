@@ -1970,7 +1970,7 @@ class _Conv3x3S2(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_x or need_w:
-            up = torch.zeros((B, Cout, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+            up = torch.empty((B, Cout, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last).zero_()
             up[:, :, ::2, ::2] = dy
             if need_x:
                 dx = _conv3x3_call(up, _dgrad_weight(weight), None, B, H, W, Cout, Cin, "conv3x3_dgrad")
