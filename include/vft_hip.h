@@ -99,7 +99,7 @@ int vft_lora_fwd(const void* x, void* y, const void* lora_down, const void* lora
                  void* up_t_out, const void* residual, int M, int K, int N, int r, int64_t ldx,
                  int64_t ldy, int64_t ldres, float scale, void* stream);
 /* t[M][r] = scale * (x . lora_down^T) only: the adapter's low-rank activations, for consumers that apply the update
- * themselves (vft_geglu_lora_*, the rank extension of vft_linear_fwd / vft_linear_nf4); scale = alpha / rank lets the
+ * themselves (the rank extension of vft_linear_fwd / vft_linear_nf4); scale = alpha / rank lets the
  * consumer use lora_up as stored (peft/lora.py:92-104), scale = 1 gives the plain activations. */
 int vft_lora_down(const void* x, const void* lora_down, void* t_out, int M, int K, int r, int64_t ldx,
                   float scale, void* stream);
@@ -248,18 +248,6 @@ int vft_groupnorm_nhwc_bwd(const void* x, const void* dy, const float* stats, co
  */
 int vft_geglu_fwd(const void* proj, void* out, int64_t M, int F, void* stream);
 int vft_geglu_bwd(const void* proj, const void* dy, void* dproj, int64_t M, int F, void* stream);
-/* GEGLU that applies the producing projection's LoRA update on the fly (r <= 8):
- *   out = geglu(bf16(proj + scale * t . lora_up^T));  _bwd recomputes it and writes dproj[M][2F].
- * Saves the read-modify-write pass of the adapter over the (M, 8C) projection (peft/lora.py:92-104 followed by
- * sdxl/denoiser.py:183-186). */
-int vft_geglu_lora_fwd(const void* proj, const void* t, const void* lora_up, void* out, int64_t M, int F, int r,
-                       float scale, void* stream);
-/* u2 [M][r2], lora_down2 [r2][F], scale2 (optional): the LoRA data gradient of the projection that consumes the GEGLU
- * output (ff.net.2), applied to dy on the fly (dy + scale2 * u2 . lora_down2) so that layer skips its own
- * read-modify-write pass over the (M, 4C) gradient. */
-int vft_geglu_lora_bwd(const void* proj, const void* t, const void* lora_up, const void* dy, void* dproj,
-                       int64_t M, int F, int r, float scale, const void* u2, const void* lora_down2, int r2,
-                       float scale2, void* stream);
 int vft_swiglu_fwd(const void* a, const void* b, void* out, int64_t n, void* stream);
 int vft_swiglu_bwd(const void* a, const void* b, const void* dy, void* da, void* db, int64_t n, void* stream);
 int vft_gate_residual(const void* residual, const void* gate, const void* y, void* out, int64_t rows,
@@ -326,26 +314,13 @@ int vft_linear_variant(int variant);
  * tile (same K order per output element), only the speed does. */
 int vft_linear_tile_hint(int M, int N, int K, int conv, int cfg);
 
-/* ---- GEMM (bf16 / NF4 weight) ----------------------------------------------------------------
- * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, weight B row-major [out,in]
- * as nn.Linear stores it.  K % 64 == 0, N % 4 == 0.
- * vft_gemm_nt_bf16: bf16 weight (replaces nn.Linear -> cuBLAS on the denoisers' projections).
- * vft_gemm_nf4:     weight in the bitsandbytes NF4 layout (replaces bnb.nn.Linear4bit.forward ->
- *                   bnb.matmul_4bit, src/modules/quant/bnb.py:37-129): packed uint8 (element 2i in the
- *                   high nibble), blocksize 64, absmax either fp32 [nblocks] (absmax_is_u8 = 0) or
- *                   double-quantised uint8 [nblocks] with nested_absmax fp32 [ceil(nblocks/256)],
- *                   nested_code fp32 [256] and nested_offset; code = the 16-entry NF4 quant_map.
- *                   The dequantisation happens inside the GEMM's staging prologue.
- *                   transpose_w = 0:  c[M,out] = a[M,in]  . W^T (+bias)     (forward)
- *                   transpose_w = 1:  c[M,in]  = a[M,out] . W               (data gradient)
- * vft_nf4_dequant:  out[out,in] bf16 = dequantised weight (tests / tooling).
+/* ---- NF4 -> bf16 materialisation ---------------------------------------------------------------
+ * out[out,in] bf16 = dequantised weight in the bitsandbytes NF4 layout (src/modules/quant/bnb.py:37-129 ->
+ * bnb.functional.dequantize_4bit): packed uint8 (element 2i in the high nibble), blocksize 64, absmax either fp32
+ * [nblocks] (absmax_is_u8 = 0) or double-quantised uint8 [nblocks] with nested_absmax fp32 [ceil(nblocks/256)],
+ * nested_code fp32 [256] and nested_offset; code = the 16-entry NF4 quant_map.  The training path never calls it
+ * (vft_linear_nf4 dequantises inside the GEMM launch): compute-cache option, odd-shape fallback, tests, tooling.
  */
-int vft_gemm_nt_bf16(const void* a, const void* b, void* c, const void* bias, int M, int N, int K,
-                     int64_t lda, int64_t ldb, int64_t ldc, void* stream);
-int vft_gemm_nf4(const void* a, void* c, const void* bias, const void* packed, const void* absmax,
-                 int absmax_is_u8, const float* nested_absmax, const float* nested_code, const float* code,
-                 float nested_offset, int out_features, int in_features, int M, int64_t lda, int64_t ldc,
-                 int transpose_w, void* stream);
 int vft_nf4_dequant(void* out, const void* packed, const void* absmax, int absmax_is_u8,
                     const float* nested_absmax, const float* nested_code, const float* code,
                     float nested_offset, int out_features, int in_features, void* stream);

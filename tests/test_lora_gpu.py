@@ -214,8 +214,8 @@ def test_lora_linear_fused_residual_and_norm_skip(gpu, M, K, N, r):
 
 @pytest.mark.parametrize("M,C,r", [(1000, 640, 4), (333, 1280, 8), (77, 64, 4)])
 def test_lora_linear_geglu_fused(gpu, M, C, r):
-    """geglu(LoRALinear(x)) with the adapter applied inside the GEGLU kernel (vft_lora_down + vft_geglu_lora_*)
-    vs the fp32 composition: output, input gradient and both adapter gradients."""
+    """geglu(LoRALinear(x)) through kernels.lora_linear_geglu vs the fp32 composition: output, input gradient and both
+    adapter gradients (both LoRA compositions, see the `lora_path` fixture)."""
     import torch.nn.functional as F
 
     from vision_ft_amd import kernels
@@ -291,8 +291,8 @@ def test_lora_qkv_fused_projection(gpu):
 
 @pytest.mark.parametrize("M,C,r", [(1000, 640, 4), (333, 1280, 8)])
 def test_lora_geglu_down_fused_feedforward(gpu, M, C, r):
-    """x + down(geglu(up(x))) with both adapters folded into the GEGLU kernels (kernels.lora_geglu_down) equals the
-    step-by-step composition (lora_linear -> geglu -> lora_linear with residual): output and every gradient."""
+    """x + down(geglu(up(x))) as the SDXL FeedForward calls it (kernels.lora_geglu_down) equals the step-by-step
+    composition (lora_linear -> geglu -> lora_linear with residual): output and every gradient."""
     from vision_ft_amd import kernels
 
     g = torch.Generator().manual_seed(31)

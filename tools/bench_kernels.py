@@ -160,7 +160,7 @@ def gemm():
     for M, N, K in [(65536, 640, 640), (16384, 1280, 1280), (16384, 10240, 1280), (16384, 1280, 5120), (65536, 5120, 640),
                     (17408, 3840, 2304), (17408, 9216, 2304), (17408, 2304, 9216), (8720, 3072, 3072), (8720, 8192, 3072)]:
         x, w, b = bf(M, K), bf(N, K), bf(N)
-        to = timeit(lambda: kernels.gemm_nt(x, w, b), iters=10)
+        to = timeit(lambda: kernels.linear_fused(x, w, b), iters=10)
         tl = timeit(lambda: F.linear(x, w, b), iters=10)
         fl = 2.0 * M * N * K
         line = f"M={M:6d} N={N:5d} K={K:5d} | ours {to*1e6:8.1f} us {fl/to/1e12:7.1f} TF/s | hipBLASLt {tl*1e6:8.1f} us {fl/tl/1e12:7.1f} TF/s"
@@ -173,9 +173,7 @@ def gemm():
             dy = bf(M, N)
             tq = timeit(lambda: kernels._nf4_gemm(x, st, None, False), iters=10)
             tqt = timeit(lambda: kernels._nf4_gemm(dy, st, None, True), iters=10)
-            tq1 = timeit(lambda: kernels._nf4_gemm_v1(x, st, None, False), iters=10)
-            tqt1 = timeit(lambda: kernels._nf4_gemm_v1(dy, st, None, True), iters=10)
-            line += f" | nf4 fwd {fl/tq/1e12:6.1f} dgrad {fl/tqt/1e12:6.1f} TF/s (v1 {fl/tq1/1e12:5.1f} / {fl/tqt1/1e12:5.1f})"
+            line += f" | nf4 fwd {fl/tq/1e12:6.1f} dgrad {fl/tqt/1e12:6.1f} TF/s"
         print(line)
 
 

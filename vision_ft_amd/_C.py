@@ -44,8 +44,6 @@ SIGNATURES: dict[str, tuple] = {
     "vft_lora_down": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_int64, c_float, c_void_p]),
     "vft_lora_down_variant": (c_int, [c_int]),
     "vft_lora_wgrad_target": (c_int, [c_int]),
-    "vft_geglu_lora_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_float, c_void_p]),
-    "vft_geglu_lora_bwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "vft_lora_bwd_dx": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
     "vft_lora_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vft_lora_wgrad2": (c_int, [c_void_p] * 7 + [c_size_t] + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p]),
@@ -88,8 +86,6 @@ SIGNATURES: dict[str, tuple] = {
     "vft_linear_variant": (c_int, [c_int]),
     "vft_linear_tile_hint": (c_int, [c_int] * 5),
     "vft_attn_variant": (c_int, [c_int]),
-    "vft_gemm_nt_bf16": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_int64] * 3 + [c_void_p]),
-    "vft_gemm_nf4": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_float, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
     "vft_nf4_dequant": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_float, c_int, c_int, c_void_p]),
 }
 

@@ -56,6 +56,7 @@ struct AttnParams {
     int64_t ds_ld;
     float* dq_ws;           // stored-dS form: fp32 partial tiles of the batched dQ GEMM
     int nsplit;
+    int dbg;                // timing experiments only (VFT_ATTN_DEBUG, read by launch_bwd1): WRONG results when non-zero
     int B, Hq, Hkv, Sq, Sk;
     float scale;
     Str3 sq, sk, sv, so, sdo, sdq, sdk, sdv;
@@ -2503,8 +2504,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     int vq_lane = st_r * qs_s * 2 + st_c, vdo_lane = st_r * dos_s * 2 + st_c, vst_lane = lane * 4;
     __amdgpu_buffer_rsrc_t hrq = __builtin_amdgcn_make_buffer_rsrc((void*)p.q, 0, 0, 0x00020000), hrdo = hrq, hrs = hrq;
     auto head_rsrc = [&](int gq) {  // (gq >= G: past the last head — empty descriptors, every DMA of a dead tile reads zeros)
-        const bool livehead = gq < G;
-        const int hq = hkv * G + (livehead ? gq : 0);
+        const bool livehead = gq < G && !(p.dbg & 8);
+        const int hq = hkv * G + (gq < G ? gq : 0);
         hrq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + b * p.sq.b + hq * p.sq.h), 0, livehead ? (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2) : 0, 0x00020000);
         hrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dout + b * p.sdo.b + hq * p.sdo.h), 0, livehead ? (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2) : 0, 0x00020000);
         hrs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.nlse : p.delta) + ((int64_t)b * p.Hq + hq) * p.Sq), 0, (livehead && w < 2) ? p.Sq * 4 : 0, 0x00020000);
@@ -2617,7 +2618,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         // descriptor over the pair's niter tiles, the tile number times 16 KiB in the lane offset; past the last tile the
         // offset is past the descriptor (zeros); in the range's first key block there is nothing to read (empty descriptor)
         float* const pair_scr = scr + tile_id_of(0) * (BQ * D);
-        const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, first ? 0 : niter * (BQ * D * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, (first || (p.dbg & 1)) ? 0 : niter * (BQ * D * 4), 0x00020000);
         const int old_lane = ((w & 3) * 1024 + (2 * kh) * 256 + lane * 4) * 4;
         auto old_dma = [&](int it) {
             if constexpr (LEAN) {
@@ -2761,6 +2762,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 }
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
+                    if (LEAN && (p.dbg & 2) && kk >= 1) break;
                     const bf16x8 a_ = ka[kk % QF], b_ = sa[kk % QF];
                     if (kk + QF < 8) {
                         ka[kk % QF] = trfrag(kim + (kk + QF) * 16 * RB, dtw);
@@ -2812,8 +2814,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 }
             } else if constexpr (LEAN) {
                 float* s0 = pair_scr + (int64_t)it * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
-                *reinterpret_cast<f32x4*>(s0) = sum0;
-                *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
+                if (!(p.dbg & 1)) {
+                    *reinterpret_cast<f32x4*>(s0) = sum0;
+                    *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
+                }
             } else {
                 float* s0 = scr_ptr(it);
                 *reinterpret_cast<f32x4*>(s0) = sum0;
@@ -2989,6 +2993,10 @@ int launch_bwd1(AttnParams p, hipStream_t st) {
     const int64_t rows = (int64_t)p.B * p.Hq * p.Sq * (D / 8);
     hipLaunchKernelGGL(attn_delta_kernel<D>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
     VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
+    {
+        const char* e = getenv("VFT_ATTN_DEBUG");
+        p.dbg = e ? atoi(e) : 0;
+    }
     if (g_attn_variant == 5)  // A/B: the round-3/4 per-tile bookkeeping
         hipLaunchKernelGGL((attn_bwd1_kernel<D, false>), dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
     else

@@ -58,168 +58,6 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     }
 }
 
-// GEGLU with the producing projection's LoRA update applied on the fly:
-//     p_eff[m][n] = bf16(proj[m][n] + s * Σ_j t[m][j] * B[n][j]),   out = p_eff[:, :F] * gelu(p_eff[:, F:])
-// so the adapter of the (C -> 8C) GEGLU projection never costs a read-modify-write pass over the widest
-// activation of the block (the reference materialises it: peft/lora.py:92-104 then sdxl/denoiser.py:183-186).
-// One workgroup = 16 token rows; a thread owns 8 value + 8 gate columns with their 2x8xr coefficients in
-// registers and walks the rows (the lora_rows_kernel phase-2 map).  BWD recomputes p_eff and writes dproj.
-template <int RC, bool BWD>
-__global__ __launch_bounds__(256) void geglu_lora_kernel(const bf16_t* __restrict__ proj, const bf16_t* __restrict__ t,
-                                                         const bf16_t* __restrict__ Bw, const bf16_t* __restrict__ dy,
-                                                         bf16_t* __restrict__ out, int M, int F, int r, float s,
-                                                         const bf16_t* __restrict__ u2, const bf16_t* __restrict__ A2, int r2,
-                                                         float s2) {
-    // (BWD only, optional) u2 [M][r2], A2 [r2][F], s2: the consuming projection's LoRA data gradient, applied to dy on
-    // the fly:  dy_eff = dy + s2 * u2 . A2  — that layer then skips its read-modify-write pass over the (M, 4C) gradient
-    constexpr int HP = RC / 2;
-    __shared__ bf16x2 ts[16][HP + 1];  // the block's rank-r activations as bf16 pairs
-    __shared__ bf16x2 us[16][HP + 1];  // BWD with u2: the block's rows of u2 as bf16 pairs
-    const int tid = threadIdx.x;
-    const int m0 = blockIdx.x * 16;
-    const int nrows = min(16, M - m0);
-    if (tid < 16 * HP) {
-        const int row = tid / HP, jj = tid % HP;
-        bf16x2 pr;
-        pr[0] = (row < nrows && 2 * jj < r) ? t[(int64_t)(m0 + row) * r + 2 * jj] : (bf16_t)0.f;
-        pr[1] = (row < nrows && 2 * jj + 1 < r) ? t[(int64_t)(m0 + row) * r + 2 * jj + 1] : (bf16_t)0.f;
-        ts[row][jj] = pr;
-        if (BWD && u2 != nullptr) {
-            bf16x2 pu;
-            pu[0] = (row < nrows && 2 * jj < r2) ? u2[(int64_t)(m0 + row) * r2 + 2 * jj] : (bf16_t)0.f;
-            pu[1] = (row < nrows && 2 * jj + 1 < r2) ? u2[(int64_t)(m0 + row) * r2 + 2 * jj + 1] : (bf16_t)0.f;
-            us[row][jj] = pu;
-        }
-    }
-    __syncthreads();
-    const int G = F >> 3;
-    const int npass = (G + 127) >> 7;
-    const int cw = (G + npass - 1) / npass;
-    const int rp = 256 / cw;
-    const int lr = tid / cw, lc = tid - lr * cw;
-    if (lr >= rp) return;
-    for (int c0 = 0; c0 < G; c0 += cw) {
-        if (c0 + lc >= G) break;
-        const int f0 = (c0 + lc) * 8;
-        // coefficients of the thread's 8 value and 8 gate columns as bf16 pairs (two MACs per v_dot2c_f32_bf16)
-        bf16x2 wa[8][HP], wg[8][HP];
-        if (r == RC) {  // contiguous runs of 8*r elements: RC 16-byte loads each
-            bf16x8 va[RC], vg[RC];
-#pragma unroll
-            for (int q = 0; q < RC; ++q) {
-                va[q] = *reinterpret_cast<const bf16x8*>(Bw + (int64_t)f0 * RC + 8 * q);
-                vg[q] = *reinterpret_cast<const bf16x8*>(Bw + (int64_t)(F + f0) * RC + 8 * q);
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-                for (int jj = 0; jj < HP; ++jj) {
-                    bf16x2 x2, y2;
-                    x2[0] = va[(c * RC + 2 * jj) >> 3][(c * RC + 2 * jj) & 7];
-                    x2[1] = va[(c * RC + 2 * jj + 1) >> 3][(c * RC + 2 * jj + 1) & 7];
-                    y2[0] = vg[(c * RC + 2 * jj) >> 3][(c * RC + 2 * jj) & 7];
-                    y2[1] = vg[(c * RC + 2 * jj + 1) >> 3][(c * RC + 2 * jj + 1) & 7];
-                    wa[c][jj] = x2;
-                    wg[c][jj] = y2;
-                }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-                for (int jj = 0; jj < HP; ++jj) {
-                    bf16x2 x2, y2;
-                    x2[0] = 2 * jj < r ? Bw[(int64_t)(f0 + c) * r + 2 * jj] : (bf16_t)0.f;
-                    x2[1] = 2 * jj + 1 < r ? Bw[(int64_t)(f0 + c) * r + 2 * jj + 1] : (bf16_t)0.f;
-                    y2[0] = 2 * jj < r ? Bw[(int64_t)(F + f0 + c) * r + 2 * jj] : (bf16_t)0.f;
-                    y2[1] = 2 * jj + 1 < r ? Bw[(int64_t)(F + f0 + c) * r + 2 * jj + 1] : (bf16_t)0.f;
-                    wa[c][jj] = x2;
-                    wg[c][jj] = y2;
-                }
-        }
-        bf16x2 wd[8][HP];  // BWD with u2: A2[2jj .. 2jj+1][f0 + c]
-        if (BWD && u2 != nullptr) {
-#pragma unroll
-            for (int jj = 0; jj < HP; ++jj) {
-                bf16x8 ra, rb;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ra[e] = rb[e] = (bf16_t)0.f;
-                if (2 * jj < r2) ra = *reinterpret_cast<const bf16x8*>(A2 + (int64_t)(2 * jj) * F + f0);
-                if (2 * jj + 1 < r2) rb = *reinterpret_cast<const bf16x8*>(A2 + (int64_t)(2 * jj + 1) * F + f0);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    bf16x2 t2;
-                    t2[0] = ra[c];
-                    t2[1] = rb[c];
-                    wd[c][jj] = t2;
-                }
-            }
-        }
-        // rows in batches of NB: every load of a batch is in flight before the first MAC
-        constexpr int NB = BWD ? 2 : 4;
-        for (int i0 = lr; i0 < nrows; i0 += NB * rp) {
-            float a[NB][8], g[NB][8], d[BWD ? NB : 1][8];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int i = i0 + b * rp;
-                if (i < nrows) {
-                    const int64_t m = m0 + i;
-                    ld8(proj + m * 2 * F + f0, a[b]);
-                    ld8(proj + m * 2 * F + F + f0, g[b]);
-                    if (BWD) ld8(dy + m * F + f0, d[b]);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int i = i0 + b * rp;
-                if (i >= nrows) break;
-                const int64_t m = m0 + i;
-                bf16x2 tp[HP];
-#pragma unroll
-                for (int jj = 0; jj < HP; ++jj) tp[jj] = ts[i][jj];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float da_ = 0.f, dg_ = 0.f;
-#pragma unroll
-                    for (int jj = 0; jj < HP; ++jj) {
-                        da_ = __builtin_amdgcn_fdot2_f32_bf16(wa[c][jj], tp[jj], da_, false);
-                        dg_ = __builtin_amdgcn_fdot2_f32_bf16(wg[c][jj], tp[jj], dg_, false);
-                    }
-                    a[b][c] = (float)(bf16_t)fmaf(s, da_, a[b][c]);  // the projection output is a bf16 tensor in the reference
-                    g[b][c] = (float)(bf16_t)fmaf(s, dg_, g[b][c]);
-                }
-                if (!BWD) {
-                    float o[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) o[c] = a[b][c] * gelu_f(g[b][c]);
-                    st8(out + m * F + f0, o);
-                } else {
-                    if (u2 != nullptr) {
-                        bf16x2 up[HP];
-#pragma unroll
-                        for (int jj = 0; jj < HP; ++jj) up[jj] = us[i][jj];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            float dd = 0.f;
-#pragma unroll
-                            for (int jj = 0; jj < HP; ++jj) dd = __builtin_amdgcn_fdot2_f32_bf16(wd[c][jj], up[jj], dd, false);
-                            d[b][c] = fmaf(s2, dd, d[b][c]);
-                        }
-                    }
-                    float da[8], dg[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float gl, dgl;
-                        gelu_both(g[b][c], gl, dgl);
-                        da[c] = d[b][c] * gl;
-                        dg[c] = d[b][c] * a[b][c] * dgl;
-                    }
-                    st8(out + m * 2 * F + f0, da);
-                    st8(out + m * 2 * F + F + f0, dg);
-                }
-            }
-        }
-    }
-}
 
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                          bf16_t* __restrict__ out, int64_t nvec) {
@@ -323,51 +161,6 @@ extern "C" int vft_gate_residual(const void* residual, const void* gate, const v
     return 0;
 }
 
-static int geglu_lora_args(const char* name, const void* proj, const void* t, const void* lora_up, const void* out, int64_t M,
-                           int F, int r) {
-    VFT_CHECK_ARG(proj && t && lora_up && out, "%s: null pointer", name);
-    VFT_CHECK_ARG(M > 0 && M < (1LL << 31) && F > 0 && F % 8 == 0 && r > 0 && r <= 8, "%s: need 0 < M < 2^31, F %% 8 == 0, 0 < r <= 8 (M=%lld F=%d r=%d)",
-                  name, (long long)M, F, r);
-    VFT_CHECK_ARG((((uintptr_t)proj | (uintptr_t)out) & 15) == 0, "%s: activations must be 16-byte aligned", name);
-    return 0;
-}
-
-// out[M][F] = geglu(proj[M][2F] + scale * t[M][r] . lora_up[2F][r]^T)
-extern "C" int vft_geglu_lora_fwd(const void* proj, const void* t, const void* lora_up, void* out, int64_t M, int F, int r,
-                                  float scale, void* stream) {
-    if (geglu_lora_args("vft_geglu_lora_fwd", proj, t, lora_up, out, M, F, r)) return 1;
-    const dim3 grid((unsigned)((M + 15) / 16));
-    if (r <= 4)
-        hipLaunchKernelGGL((geglu_lora_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale, nullptr, nullptr, 0, 0.f);
-    else
-        hipLaunchKernelGGL((geglu_lora_kernel<8, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, nullptr, (bf16_t*)out, (int)M, F, r, scale, nullptr, nullptr, 0, 0.f);
-    VFT_CHECK_LAUNCH("vft_geglu_lora_fwd");
-    return 0;
-}
-
-// dproj[M][2F] from dy[M][F], recomputing the adapted projection
-extern "C" int vft_geglu_lora_bwd(const void* proj, const void* t, const void* lora_up, const void* dy, void* dproj, int64_t M,
-                                  int F, int r, float scale, const void* u2, const void* lora_down2, int r2, float scale2,
-                                  void* stream) {
-    if (geglu_lora_args("vft_geglu_lora_bwd", proj, t, lora_up, dproj, M, F, r)) return 1;
-    VFT_CHECK_ARG(dy != nullptr && ((uintptr_t)dy & 15) == 0, "vft_geglu_lora_bwd: bad dy pointer");
-    VFT_CHECK_ARG((u2 == nullptr) == (lora_down2 == nullptr), "vft_geglu_lora_bwd: u2 and lora_down2 go together");
-    VFT_CHECK_ARG(u2 == nullptr || (r2 > 0 && r2 <= (r <= 4 ? 4 : 8) && ((uintptr_t)lora_down2 & 15) == 0),
-                  "vft_geglu_lora_bwd: the consumer's rank (%d) must fit this launch's rank chunk and lora_down2 be 16-byte aligned", r2);
-    const dim3 grid((unsigned)((M + 15) / 16));
-    if (r <= 4)
-        hipLaunchKernelGGL((geglu_lora_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale,
-                           (const bf16_t*)u2, (const bf16_t*)lora_down2, r2, scale2);
-    else
-        hipLaunchKernelGGL((geglu_lora_kernel<8, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)proj,
-                           (const bf16_t*)t, (const bf16_t*)lora_up, (const bf16_t*)dy, (bf16_t*)dproj, (int)M, F, r, scale,
-                           (const bf16_t*)u2, (const bf16_t*)lora_down2, r2, scale2);
-    VFT_CHECK_LAUNCH("vft_geglu_lora_bwd");
-    return 0;
-}
 
 // ---------------------------------------------------------------------------------------------
 // dst[C][R] = src[R][C]^T (bf16): the per-step transposed copy of a TRAINABLE projection weight, on which the data gradient

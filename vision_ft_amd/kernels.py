@@ -1402,144 +1402,17 @@ class _QLoRALinear(torch.autograd.Function):
         return dx, None, dA, dB, None, None, dres, None
 
 
-class _LoRALinearDeferred(torch.autograd.Function):
-    """(x Wᵀ + b, t = x Aᵀ): the base projection and the adapter's low-rank activations; the update
-    s·t·Bᵀ is applied by the consumer (`geglu_lora`).  Since d(loss)/d(base output) = d(loss)/d(adapted output),
-    the backward is that of `_LoRALinear` with the consumer's input gradient as dy."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, A, B, s):
-        x2 = _rows(x)
-        A = A.contiguous()
-        with torch.cuda.device(x.device):
-            y2 = F.linear(x2, weight, bias)
-            t = lora_down(x2, A)
-        ctx.save_for_backward(x2, t, weight, A, B)
-        ctx.s = s
-        ctx.xshape = x.shape
-        ctx.mark_non_differentiable(t)
-        return y2.view(*x.shape[:-1], weight.shape[0]), t
-
-    @staticmethod
-    def backward(ctx, dy, _dt):
-        x2, t, weight, A, B = ctx.saved_tensors
-        s = ctx.s
-        dy2 = _rows(dy)
-        Bt = B.t().contiguous()
-        dx = dA = dB = None
-        with torch.cuda.device(dy.device):
-            if ctx.needs_input_grad[0]:
-                dx2 = dy2 @ weight
-                u = _lora_bwd_dx_(dy2, dx2, Bt, A, s)
-                dx = dx2.view(ctx.xshape)
-            else:
-                scratch = torch.empty((dy2.shape[0], A.shape[1]), dtype=dy.dtype, device=dy.device)
-                u = _lora_bwd_dx_(dy2, scratch, Bt, A, s)
-            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-                dA, dB = _lora_wgrad2(x2, u, dy2, t, A, B.contiguous(), s)
-        return dx, None, None, dA, dB, None
-
-
-class _GeGLULoRA(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, proj, t, B, s):
-        F2 = proj.shape[-1]
-        p2 = _rows(proj)
-        if p2.stride(0) != F2:
-            p2 = p2.contiguous()
-        M, Fh = p2.shape[0], F2 // 2
-        B = B.contiguous()
-        out = torch.empty((M, Fh), dtype=torch.bfloat16, device=proj.device)
-        with torch.cuda.device(proj.device), _Timed("geglu_fwd", 6.0 * M * Fh):
-            st = _C.lib().vft_geglu_lora_fwd(_ptr(p2), _ptr(t), _ptr(B), _ptr(out), M, Fh, B.shape[1], float(s), _stream())
-        _C.check(st, "vft_geglu_lora_fwd")
-        ctx.save_for_backward(p2, t, B)
-        ctx.s = s
-        ctx.pshape = proj.shape
-        return out.view(*proj.shape[:-1], Fh)
-
-    @staticmethod
-    def backward(ctx, dy):
-        p2, t, B = ctx.saved_tensors
-        M, F2 = p2.shape
-        Fh = F2 // 2
-        dy2 = dy.reshape(M, Fh)
-        if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
-            dy2 = dy2.to(torch.bfloat16).contiguous()
-        dproj = torch.empty((M, F2), dtype=torch.bfloat16, device=dy.device)
-        with torch.cuda.device(dy.device), _Timed("geglu_bwd", 10.0 * M * Fh):
-            st = _C.lib().vft_geglu_lora_bwd(_ptr(p2), _ptr(t), _ptr(B), _ptr(dy2), _ptr(dproj), M, Fh, B.shape[1],
-                                             float(ctx.s), None, None, 0, 0.0, _stream())
-        _C.check(st, "vft_geglu_lora_bwd")
-        return dproj.view(ctx.pshape), None, None, None
-
-
-class _GeGLUDown(torch.autograd.Function):
-    """out = residual + LoRALinear_2(geglu(proj + s1·t1·B1ᵀ)) — the GEGLU and the FeedForward's output projection
-    (SDXL FeedForward.net[0..2], src/models/sdxl/denoiser.py:175-207) as one autograd node, so that the backward can
-    hand the output projection's LoRA data gradient to the GEGLU backward kernel (`u2`, `A2`): neither adapter
-    costs a read-modify-write pass over a (tokens, 4C/8C) tensor.  d(proj) flows on to `_LoRALinearDeferred`."""
-
-    @staticmethod
-    def forward(ctx, proj, t1, B1, s1, W2, b2, A2, B2, s2, residual):
-        F2 = proj.shape[-1]
-        p2 = _rows(proj)
-        if p2.stride(0) != F2:
-            p2 = p2.contiguous()
-        M, Fh = p2.shape[0], F2 // 2
-        B1, A2, B2 = B1.contiguous(), A2.contiguous(), B2.contiguous()
-        res2 = None
-        if residual is not None:
-            res2 = residual.reshape(-1, residual.shape[-1])
-            if res2.stride(-1) != 1 or res2.stride(0) % 8 != 0 or res2.dtype != torch.bfloat16:
-                res2 = res2.to(torch.bfloat16).contiguous()
-        g = torch.empty((M, Fh), dtype=torch.bfloat16, device=proj.device)
-        with torch.cuda.device(proj.device):
-            with _Timed("geglu_fwd", 6.0 * M * Fh):
-                st = _C.lib().vft_geglu_lora_fwd(_ptr(p2), _ptr(t1), _ptr(B1), _ptr(g), M, Fh, B1.shape[1], float(s1), _stream())
-            _C.check(st, "vft_geglu_lora_fwd")
-            y2 = F.linear(g, W2, b2)
-            t2, _ = _lora_fwd_(g, y2, A2, B2, s2, res2)
-        ctx.save_for_backward(p2, t1, B1, g, t2, W2, A2, B2)
-        ctx.s1, ctx.s2, ctx.pshape = s1, s2, proj.shape
-        ctx.res_shape = residual.shape if residual is not None else None
-        return y2.view(*proj.shape[:-1], W2.shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        p2, t1, B1, g, t2, W2, A2, B2 = ctx.saved_tensors
-        M, F2 = p2.shape
-        Fh = F2 // 2
-        dy2 = _rows(dy)
-        if dy2.dtype != torch.bfloat16 or dy2.stride(-1) != 1:
-            dy2 = dy2.to(torch.bfloat16).contiguous()
-        dA2 = dB2 = None
-        with torch.cuda.device(dy.device):
-            u2 = lora_down(dy2, B2.t().contiguous())       # (M, r2) = dy . B2
-            dg = dy2 @ W2                                   # base data gradient of the output projection, (M, 4C)
-            dproj = torch.empty((M, F2), dtype=torch.bfloat16, device=dy.device)
-            with _Timed("geglu_bwd", 10.0 * M * Fh):
-                st = _C.lib().vft_geglu_lora_bwd(_ptr(p2), _ptr(t1), _ptr(B1), _ptr(dg), _ptr(dproj), M, Fh, B1.shape[1],
-                                                 float(ctx.s1), _ptr(u2), _ptr(A2), A2.shape[0], float(ctx.s2), _stream())
-            _C.check(st, "vft_geglu_lora_bwd")
-            if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
-                dA2, dB2 = _lora_wgrad2(g, u2, dy2, t2, A2, B2, ctx.s2)
-        dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[9] else None
-        return dproj.view(ctx.pshape), None, None, None, None, None, dA2, dB2, None, dres
-
-
 def lora_geglu_down(x: torch.Tensor, up_base, up_A, up_B, s1: float, down_base, down_A, down_B, s2: float,
                     residual: torch.Tensor | None = None, up_pack: dict | None = None, down_pack: dict | None = None) -> torch.Tensor:
-    """residual + down(geglu(up(x))) for two LoRA-wrapped bf16 Linears (the SDXL FeedForward), fused as described in
-    `_GeGLUDown` / `_LoRALinearDeferred`."""
+    """residual + down(geglu(up(x))) for two LoRA-wrapped bf16 Linears (the SDXL FeedForward, src/models/sdxl/denoiser.py:175-207):
+    both adapters ride in their projection's GEMM (forward and data gradient), a plain GEGLU in between.  Shapes the fused
+    GEMM does not take (a dimension that is no multiple of 64) go through `lora_linear`'s general composition.  (Rounds 1-4
+    also carried a third form that applied the adapters inside special GEGLU kernels; it lost to the fused GEMM in round 2
+    and was removed in round 5 together with its kernels.)"""
     _ready(x, up_A, up_B, down_A, down_B)
     _require_gpu(x, up_A, up_B, down_A, down_B)
-    if (FUSED_LORA_GEMM and fused_lora_eligible(up_base.weight, up_A.shape[0]) and fused_lora_eligible(down_base.weight, down_A.shape[0])):
-        # both adapters ride in their projection's GEMM (forward and data gradient): plain GEGLU in between
-        proj = _LoRALinearFused.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1), None, up_pack)
-        return _LoRALinearFused.apply(geglu(proj), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual, down_pack)
-    proj, t1 = _LoRALinearDeferred.apply(x, up_base.weight, up_base.bias, up_A, up_B, float(s1))
-    return _GeGLUDown.apply(proj, t1, up_B.detach(), float(s1), down_base.weight, down_base.bias, down_A, down_B, float(s2), residual)
+    proj = lora_linear(x, up_base, up_A, up_B, float(s1), None, up_pack)
+    return lora_linear(geglu(proj), down_base, down_A, down_B, float(s2), residual, down_pack)
 
 
 def lora_geglu_eligible(x: torch.Tensor, base, lora_down_w: torch.Tensor) -> bool:
@@ -1548,12 +1421,8 @@ def lora_geglu_eligible(x: torch.Tensor, base, lora_down_w: torch.Tensor) -> boo
 
 
 def lora_linear_geglu(x: torch.Tensor, base, lora_down_w: torch.Tensor, lora_up_w: torch.Tensor, scale: float) -> torch.Tensor:
-    """geglu(base(x) + scale * (x @ lora_down^T) @ lora_up^T) without materialising the adapted projection: the
-    base GEMM, the rank-r activations, and a GEGLU kernel that applies the update on the fly."""
-    _ready(x, lora_down_w, lora_up_w)
-    _require_gpu(x, lora_down_w, lora_up_w)
-    proj, t = _LoRALinearDeferred.apply(x, base.weight, base.bias, lora_down_w, lora_up_w, float(scale))
-    return _GeGLULoRA.apply(proj, t, lora_up_w.detach(), float(scale))
+    """geglu(base(x) + scale * (x @ lora_down^T) @ lora_up^T)."""
+    return geglu(lora_linear(x, base, lora_down_w, lora_up_w, float(scale)))
 
 
 class _LoRABranch(torch.autograd.Function):
@@ -1621,20 +1490,6 @@ def lora_linear(x: torch.Tensor, base, lora_down: torch.Tensor, lora_up: torch.T
 # =============================================================================================
 # GEMM on our MFMA kernel (bf16 weight) and NF4-fused linear
 # =============================================================================================
-def gemm_nt(x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """x2 [M,K] @ weight[N,K]^T (+bias) with the hand-written MFMA kernel (vft_gemm_nt_bf16)."""
-    _ready(x2, weight)
-    _require_gpu(x2, weight, bias)
-    M, K = x2.shape
-    N = weight.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
-    with torch.cuda.device(x2.device), _Timed("gemm_nt_bf16", 2.0 * M * N * K):
-        st = _C.lib().vft_gemm_nt_bf16(_ptr(x2), _ptr(weight), _ptr(out), _ptr(bias), M, N, K, x2.stride(0),
-                                       weight.stride(0), out.stride(0), _stream())
-    _C.check(st, "vft_gemm_nt_bf16")
-    return out
-
-
 # Problem sizes seen by the fused GEMM / implicit-GEMM convolution (tools/tune_lin8.py switches this on for one step of
 # each workload to know what to time): None = off, else a set of ("lin", M, N, K) / ("conv", B, H, W, Cin, Cout).
 SHAPE_LOG: set | None = None
@@ -2262,20 +2117,6 @@ class NF4State:
         return self._absmax_f32
 
 
-def _nf4_gemm_v1(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool) -> torch.Tensor:
-    """First-generation NF4 GEMM (vft_gemm_nf4: 128x128 register-staged tile); kept for A/B and tests."""
-    M = a2.shape[0]
-    N = q.in_features if transpose_w else q.out_features
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
-    K = q.out_features if transpose_w else q.in_features
-    with torch.cuda.device(a2.device), _Timed("gemm_nf4_v1", 2.0 * M * N * K):
-        st = _C.lib().vft_gemm_nf4(_ptr(a2), _ptr(out), _ptr(bias), _ptr(q.packed), _ptr(q.absmax), int(q.absmax_is_u8),
-                                   _ptr(q.nested_absmax), _ptr(q.nested_code), _ptr(q.code), q.offset, q.out_features,
-                                   q.in_features, M, a2.stride(0), out.stride(0), int(transpose_w), _stream())
-    _C.check(st, "vft_gemm_nf4")
-    return out
-
-
 # NF4 GEMM form (modules/quant/nf4.py documents the switch): True = the launch dequantises the weight ONCE into a transient bf16
 # workspace (all workgroups share the work, grid barrier, then the bf16 main loop of lin8); False = round 3's form, codes
 # dequantised inside the K-loop by every row tile.  Either way the 4-bit codes are the only copy that persists in HBM.
@@ -2353,7 +2194,10 @@ def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None
     N = q.in_features if transpose_w else q.out_features
     K = q.out_features if transpose_w else q.in_features
     if K % 64 != 0:
-        return _nf4_gemm_v1(a2, q, bias, transpose_w)
+        # a reduction dimension the dequantising GEMM does not take (none in the three models): dense copy + library GEMM
+        w = nf4_dequantize(q)
+        out = a2 @ (w if transpose_w else w.t())
+        return out if bias is None else out + bias
     out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
     r = ext_x.shape[1] if ext_x is not None else 0
     ws, ws_bytes = None, 0

@@ -156,9 +156,8 @@ class CrossAttention(nn.Module):
         return self.to_out[1](_proj_residual(self.to_out[0], _merge_heads(attn), residual))
 
 
-# Apply the GEGLU projection's LoRA update inside the GEGLU kernel (vft_lora_down + vft_geglu_lora_*) instead of a
-# read-modify-write pass over the (M, 8C) projection.  Measured on MI355X (B=24, 1024²): +2.3 % end to end once the
-# GEGLU kernels stopped being VALU-bound on erf (before that the fusion was neutral).
+# The FeedForward's two LoRA-wrapped projections as one call (kernels.lora_geglu_down): both adapters inside their
+# projection's GEMM, a plain GEGLU kernel in between, the block's skip connection in the output projection's epilogue.
 FUSE_LORA_INTO_GEGLU = True
 FUSE_CROSS_KV = os.environ.get("VFT_FUSE_KV", "1") != "0"  # A/B switch: to_k | to_v of the cross-attention context as one GEMM
 
@@ -172,7 +171,6 @@ class GeGLU(nn.Module):
         p = self.proj
         if (FUSE_LORA_INTO_GEGLU and isinstance(p, LoRALinear) and p.enabled and not p.training_dropout_active()
                 and kernels.lora_geglu_eligible(hidden_states, p.linear, p.lora_down.weight)):
-            # the adapter's update is applied inside the GEGLU kernel: no extra pass over the (M, 8C) projection
             return kernels.lora_linear_geglu(hidden_states, p.linear, p.lora_down.weight, p.lora_up.weight, p._scale())
         return kernels.geglu(_proj(p, hidden_states))
 
@@ -192,8 +190,6 @@ class FeedForward(nn.Module):
                 and kernels.lora_geglu_eligible(hidden_states, up.linear, up.lora_down.weight)
                 and type(down.linear) is nn.Linear and down.linear.weight.dtype == torch.bfloat16
                 and down.rank <= (4 if up.rank <= 4 else 8)):
-            # up projection (deferred adapter) -> GEGLU applying it -> down projection, one autograd node for the last two:
-            # both adapters' wide read-modify-write passes disappear (kernels._GeGLUDown)
             return kernels.lora_geglu_down(hidden_states, up.linear, up.lora_down.weight, up.lora_up.weight, up._scale(),
                                            down.linear, down.lora_down.weight, down.lora_up.weight, down._scale(), residual,
                                            up_pack=up.__dict__.get("_vft_pack"), down_pack=down.__dict__.get("_vft_pack"))

@@ -12,8 +12,8 @@ reference sniffs for, functional.py:277-300):
                                              nested_blocksize, nested_dtype, nested_offset}
     bias                                     optional
 
-The forward/backward run ``vft_gemm_nf4``: the packed codes are dequantised inside the GEMM's staging
-prologue (no bf16 copy of the weight in HBM).  It *is* an ``nn.Linear`` subclass so LoRA targeting
+The forward/backward run ``vft_linear_nf4``: the packed codes are dequantised inside the GEMM launch (once per
+launch into a transient scratch; no bf16 copy of the weight persists in HBM).  It *is* an ``nn.Linear`` subclass so LoRA targeting
 (`isinstance(layer, nn.Linear)`, peft/functional.py:72) wraps it like the reference's bnb layer.
 """
 from __future__ import annotations
