@@ -193,3 +193,32 @@ def test_attention_stored_ds_backward(gpu, B, Hq, Hkv, Sq, Sk, D, layout):
         assert torch.equal(a, b_)
     for a, c in zip(runs[0], runs[2]):
         assert _rel(a, c) < 6e-3, _rel(a, c)
+
+
+def test_key_padding_mask_with_holes_runs_on_the_kernel(gpu):
+    """A boolean key-padding mask whose valid keys are NOT a prefix (the reference passes any mask to SDPA,
+    src/modules/attention.py:121-129): served by key compaction + the length-masked kernel; forward and all three gradients
+    against the fp32 oracle with the same mask, for the 4-D broadcast form the reference's callers build."""
+    from oracle.attention import sdpa
+    from vision_ft_amd.modules.attention import scaled_dot_product_attention
+
+    g = torch.Generator().manual_seed(12)
+    B, Hq, Hkv, Sq, Sk, D = 2, 6, 2, 150, 333, 96
+    q, k, v = (torch.randn(B, h, s, D, generator=g).to(torch.bfloat16) for h, s in ((Hq, Sq), (Hkv, Sk), (Hkv, Sk)))
+    do = torch.randn(B, Hq, Sq, D, generator=g).to(torch.bfloat16)
+    km = torch.rand(B, Sk, generator=g) > 0.35
+    mask4 = km[:, None, None, :].expand(B, Hq, Sq, Sk)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = sdpa(qr, kr, vr, mask=mask4, attention_dtype=torch.float32)
+    ref.backward(do.float())
+    qg, kg, vg = (t.to(gpu).requires_grad_(True) for t in (q, k, v))
+    out = scaled_dot_product_attention(qg, kg, vg, mask=mask4.to(gpu))
+    out.backward(do.to(gpu))
+    assert rel_err(out.cpu(), ref) < 1e-2
+    for got, want in ((qg.grad, qr.grad), (kg.grad, kr.grad), (vg.grad, vr.grad)):
+        assert rel_err(got.cpu(), want) < 2e-2
+    assert float(kg.grad[0][:, ~km[0]].abs().max()) == 0.0  # masked keys receive no gradient
+    per_query = mask4.clone()
+    per_query[0, 0, 0, 0] = ~per_query[0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        scaled_dot_product_attention(qg, kg, vg, mask=per_query.to(gpu))

@@ -341,6 +341,39 @@ def test_gemm_table_is_well_formed_and_lookup_runs_on_a_private_copy(tmp_path, m
     assert calls["file"].startswith(str(tmp_path)) and open(calls["file"]).read() == open(tuning.DEFAULT_TABLE).read()
 
 
+def test_key_compaction_serves_key_masks_with_holes_exactly():
+    """modules/attention.py::compact_keys (round 5: the reference passes any boolean mask to SDPA,
+    src/modules/attention.py:121-129; the kernel masks by length): valid keys moved to the front in order, lengths = counts;
+    masked attention over (k, v) == length-masked attention over (k', v'), and the permutation's backward is its inverse."""
+    import torch
+    import torch.nn.functional as F
+
+    from vision_ft_amd.modules.attention import _PermuteKeys, compact_keys
+
+    g = torch.Generator().manual_seed(3)
+    B, H, Sq, Sk, D = 3, 2, 5, 11, 8
+    q, k, v = (torch.randn(B, H, n, D, generator=g) for n in (Sq, Sk, Sk))
+    km = torch.rand(B, Sk, generator=g) > 0.4
+    km[1] = True          # nothing to drop
+    km[2, :] = False
+    km[2, 4] = True       # a single valid key
+    k.requires_grad_(True)
+    kc, vc, lens = compact_keys(k, v, km)
+    assert lens.tolist() == km.sum(-1).tolist() and lens.dtype == torch.int32
+    for b in range(B):
+        assert torch.equal(kc[b, :, : lens[b]], k[b][:, km[b]]) and torch.equal(vc[b, :, : lens[b]], v[b][:, km[b]])
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=km[:, None, None, :])
+    pm = torch.arange(Sk)[None, :] < lens[:, None]
+    got = F.scaled_dot_product_attention(q, kc, vc, attn_mask=pm[:, None, None, :])
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+    w = torch.randn(B, H, Sk, D, generator=g)
+    (gk,) = torch.autograd.grad((kc * w).sum(), k)
+    order = torch.argsort((~km).to(torch.uint8), dim=1, stable=True)
+    want = torch.zeros_like(k).scatter_(2, order[:, None, :, None].expand(B, H, Sk, D), w)
+    assert torch.equal(gk, want)
+    assert _PermuteKeys.apply(k.detach(), order).shape == k.shape
+
+
 def test_mask_to_kv_len_accepts_only_prefix_key_padding_masks():
     """The kernel masks by per-batch key counts; the reference accepts arbitrary masks (src/modules/attention.py:121-129),
     so whatever cannot be represented must raise instead of attending to the wrong keys."""
