@@ -212,7 +212,8 @@ def test_key_padding_mask_with_holes_runs_on_the_kernel(gpu):
     ref = sdpa(qr, kr, vr, mask=mask4, attention_dtype=torch.float32)
     ref.backward(do.float())
     qg, kg, vg = (t.to(gpu).requires_grad_(True) for t in (q, k, v))
-    out = scaled_dot_product_attention(qg, kg, vg, mask=mask4.to(gpu))
+    mask_g = km.to(gpu)[:, None, None, :].expand(B, Hq, Sq, Sk)  # the broadcast view the reference's callers build (lumina2/denoiser.py:150-155)
+    out = scaled_dot_product_attention(qg, kg, vg, mask=mask_g)
     out.backward(do.to(gpu))
     assert rel_err(out.cpu(), ref) < 1e-2
     for got, want in ((qg.grad, qr.grad), (kg.grad, kr.grad), (vg.grad, vr.grad)):
