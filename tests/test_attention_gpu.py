@@ -6,6 +6,8 @@ import torch
 
 from oracle import attention as oattn
 
+from .helpers import rel_err
+
 pytestmark = pytest.mark.gpu
 
 # tolerance for bf16 tensors vs the fp32-accumulated oracle: rtol 1.6e-2, atol 1e-2
