@@ -51,11 +51,13 @@ def per_kernel(d, counter):
         name = r["Kernel_Name"]
         if "lin8_kernel" in name:  # plain launches: 3 of the first shape, then 3 of the second; conv launches: Lb1 in the template
             import re
-            if re.search(r"false>\s*>?, true>", name) or "ELb0EEELb1E" in name:  # C8<.., false>, NF4 = true
+            m = re.search(r"C8<\d+, \d+, \d+, (true|false)(?:, (\d))?>, (true|false)>", name)  # C8<BM, BN, WAVES_M, CONV[, STRIDE]>, NF4
+            nf4 = (m.group(3) == "true") if m else bool(re.search(r"false>\s*>?, true>", name) or "ELb0EEELb1E" in name)
+            if nf4:
                 acc["lin8_nf4"] += float(r["Counter_Value"])
                 n["lin8_nf4"] += 1
                 continue
-            conv = "ELb1EE" in name or ", true>" in name
+            conv = (m.group(1) == "true") if m else ("ELb1EE" in name or ", true>" in name)
             key = "lin8_conv" if conv else ("lin8_kernel" if lin8_seen < 3 else "lin8_kernel_b")
             lin8_seen += 0 if conv else 1
             acc[key] += float(r["Counter_Value"])

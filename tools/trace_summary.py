@@ -38,13 +38,20 @@ def main():
     def cls(n):
         if n.startswith("Cijk") or n.startswith("Custom_Cijk"):
             return "gemm(hipblaslt)"
+        if "transpose_kernel" in n:
+            return "other"  # (vft_transpose_bf16: our own copy kernel, not a library convolution helper)
         if "igemm" in n or "Im2d2Col" in n or "Col2Im" in n or "SubTensorOp" in n or "transpose" in n.lower() or "ck::" in n or "naive_conv" in n:
             return "conv(miopen/ck)"
         if "wg8_" in n:
             return "weight grad(ours, wg8)"
         if "lin8_kernel" in n:
             import re
-            if re.search(r"false>\s*>?, true>", n) or "ELb0EEELb1E" in n:  # C8<.., CONV = false>, NF4 = true (round 4)
+            m = re.search(r"C8<\d+, \d+, \d+, (true|false)(?:, (\d))?>, (true|false)>", n)  # C8<BM, BN, WAVES_M, CONV[, STRIDE]>, NF4
+            if m:
+                if m.group(3) == "true":
+                    return "NF4 gemm(ours, lin8: dequantised once per launch)"
+                return "conv3x3(ours, lin8)" if m.group(1) == "true" else "linear gemm(ours, lin8)"
+            if re.search(r"false>\s*>?, true>", n) or "ELb0EEELb1E" in n:  # (mangled / older spellings)
                 return "NF4 gemm(ours, lin8: dequantised once per launch)"
             return "conv3x3(ours, lin8)" if "ELb1EE" in n or ", true>" in n else "linear gemm(ours, lin8)"
         if "linear_kernel" in n:

@@ -1900,6 +1900,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
         char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
         if constexpr (D >= 128) {
             // descriptors that start at the tile's first row and end with the head's rows (a dead tile: no bytes at all)
+            // (round 5 tried to keep these three as incrementally advanced pointers — ~60 of the loop's 134 scalar instructions
+            // are their 64-bit products — but the kernel has no scalar register left: the nine extra SGPRs pushed four lane
+            // constants into scratch, and their reload put two `s_waitcnt vmcnt(0)` at the top of every tile: DESIGN §8)
             const int row0 = t * BQ;
             const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(Qh_ + (int64_t)row0 * p.sq.s), 0, live ? (int)(((int64_t)(p.Sq - 1 - row0) * p.sq.s + D) * 2) : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)(dOh_ + (int64_t)row0 * p.sdo.s), 0, live ? (int)(((int64_t)(p.Sq - 1 - row0) * p.sdo.s + D) * 2) : 0, 0x00020000);
@@ -2032,7 +2035,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv3_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float pv = __builtin_amdgcn_exp2f(S[4 * g4 + i] * sc - l4[i] * kLog2e);
-                        if (!kval) pv = 0.f;
+                        if (!kval) pv = 0.f;  // (round 5: hoisting this select into a branch taken only by ragged key blocks, as in
+                                              //  attn_bwd1_kernel, costs this kernel a 4-register scratch reload — and with it an
+                                              //  `s_waitcnt vmcnt(0)` — at the top of every tile: it has no register to spare)
                         S[4 * g4 + i] = pv;
                         dP[4 * g4 + i] = pv * (dP[4 * g4 + i] - d4[i]);
                     }
