@@ -1,5 +1,6 @@
 """Where does attn_bwd1_kernel's time go?  Timing-only runs with parts of the kernel disabled (VFT_ATTN_DEBUG bits, WRONG
-results): 1 = no running-dQ traffic (scratch plane neither read nor written), 2 = dQ product cut to one of its eight MFMA
+results; the library must be built with the probe compiled in: `make -C vision_ft_amd/csrc clean && make -C vision_ft_amd/csrc
+EXTRA=-DVFT_ATTN_PROBE`, the shipped build ignores the variable): 1 = no running-dQ traffic (scratch plane neither read nor written), 2 = dQ product cut to one of its eight MFMA
 steps, 8 = no Q / dO / statistics staging traffic (empty descriptors: the DMAs deliver zeros).  One process, alternating.
 
     python tools/exp/attn_bwd1_probe.py"""

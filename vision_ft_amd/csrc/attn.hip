@@ -56,7 +56,7 @@ struct AttnParams {
     int64_t ds_ld;
     float* dq_ws;           // stored-dS form: fp32 partial tiles of the batched dQ GEMM
     int nsplit;
-    int dbg;                // timing experiments only (VFT_ATTN_DEBUG, read by launch_bwd1): WRONG results when non-zero
+    int dbg;                // -DVFT_ATTN_PROBE builds only (tools/exp/attn_bwd1_probe.py): VFT_ATTN_DEBUG bits, WRONG results when non-zero
     int B, Hq, Hkv, Sq, Sk;
     float scale;
     Str3 sq, sk, sv, so, sdo, sdq, sdk, sdv;
@@ -2452,7 +2452,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
 // the Q / dO re-read per key block; at 256 keys per block that is ~2.4 + 1.2 TB/s beside an MFMA-bound loop.
 // Q / dO tiles arrive by LDS-DMA in a ring of three buffers; two workgroup barriers per tile.
 // =============================================================================================
-// LEAN (round 5, the default): the per-tile bookkeeping on the scalar unit is incremental.  The ISA of the round-3/4 loop
+// Round 5: the per-tile bookkeeping on the scalar unit is incremental.  The ISA of the round-3/4 loop
 // carried 226 scalar and 213 vector instructions per 64-query tile and wave beside its 40 MFMAs — three integer divisions
 // (tile -> (query head, query tile) for the staging, the scratch plane and the final store), four buffer descriptors rebuilt
 // from 64-bit products, per-lane staging addresses and range checks recomputed per tile, a per-element key-mask select —
@@ -2460,9 +2460,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
 // against 1 280 cycles of MFMA work), not by the matrix pipe, LDS or HBM.  Now: cursors advance by one tile, descriptors
 // are rebuilt only when the query head changes, the tensors' ends are the descriptors' ends (rows past them read zeros by
 // the hardware range check), the scratch plane of a (batch, kv head) pair is ONE descriptor indexed by the tile number, and
-// the key mask is applied only in a ragged key block.  LEAN = false keeps the old bookkeeping for A/B (vft_attn_variant(5)).
-template <int D, bool LEAN = true>
+// the key mask is applied only in a ragged key block: 653 -> ~460 instructions per tile and wave.  Measured (A/B of the two
+// forms in one process, gpurun_out/r5d): 3.872 -> 3.734 ms at B24 H10 S4096, 0.580 -> 0.564 ms at B24 H20 S1024 — a 30 %
+// shorter instruction stream buys 3-4 %: the kernel is NOT bound by instruction issue.  What it is bound by, from timing
+// runs with parts switched off (tools/exp/attn_bwd1_probe.py, build with -DVFT_ATTN_PROBE; S4096: 3.82 ms whole; 3.36
+// without the running-dQ traffic; 3.10 without the Q / dO staging traffic; 2.96 without both; 2.73 with the dQ product cut
+// to an eighth as well): ~0.9 ms of memory stalls (12.4 GB per launch at 3.2 TB/s, planes + Q / dO of 240 workgroups that
+// share nothing), and a 2.7 ms core in which the eight waves run M1 -> softmax -> M2 in lock step between two workgroup
+// barriers per tile (both waves of a SIMD want the matrix pipe, then both the vector ALU): DESIGN §10.
+template <int D>
 __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
+#ifdef VFT_ATTN_PROBE
+    const int dbg = p.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
     static_assert(D == 64, "the one-pass backward is built for head_dim 64 (register budget at two waves per SIMD)");
     constexpr int KS = D / 16, DT = D / 32, RB = D * 2, BQ = 64, QT = BQ / 32, KB = 256, NB = 3;
     constexpr int TILE = BQ * RB;                 // bytes of one Q (or dO) tile
@@ -2500,7 +2512,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     const int64_t plane = (int64_t)p.B * p.Hq * nqt * (BQ * D);   // floats per scratch plane
     float* const scr = p.split_ws + (int64_t)split * plane;
 
-    // ---- LEAN staging state: the cursor (query head of the kv group, query tile) of the next tile to stage, the descriptors
+    // ---- staging state: the cursor (query head of the kv group, query tile) of the next tile to stage, the descriptors
     //      of that head (Q, dO from the head's first row to its last; -lse/scale or -delta for waves 0 / 1, empty for the
     //      others), and this lane's fixed part of the addresses (Stage: one 1 KiB piece per wave = rows 8 w .. 8 w + 7)
     int sg = 0, stl = 0;
@@ -2509,7 +2521,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     int vq_lane = st_r * qs_s * 2 + st_c, vdo_lane = st_r * dos_s * 2 + st_c, vst_lane = lane * 4;
     __amdgpu_buffer_rsrc_t hrq = __builtin_amdgcn_make_buffer_rsrc((void*)p.q, 0, 0, 0x00020000), hrdo = hrq, hrs = hrq;
     auto head_rsrc = [&](int gq) {  // (gq >= G: past the last head — empty descriptors, every DMA of a dead tile reads zeros)
-        const bool livehead = gq < G && !(p.dbg & 8);
+        const bool livehead = gq < G && !(dbg & 8);
         const int hq = hkv * G + (gq < G ? gq : 0);
         hrq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + b * p.sq.b + hq * p.sq.h), 0, livehead ? (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2) : 0, 0x00020000);
         hrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dout + b * p.sdo.b + hq * p.sdo.h), 0, livehead ? (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2) : 0, 0x00020000);
@@ -2534,28 +2546,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     };
     // this wave's share of tile `it` (all out of range past the end): Q, dO, and one 4-byte DMA — wave 0 the tile's 64
     // -lse / scale values, wave 1 its -delta values (both prepared by attn_delta_kernel), the others a filler
-    auto stage = [&](int it, int buf) {
-        if constexpr (LEAN) {
-            stage_lean(buf);
-            return;
-        }
-        const bool live = it < niter;
-        const int itc = live ? it : 0;
-        const int gq = itc / nqt, t = itc % nqt;
-        const int hq = hkv * G + gq;
-        const bf16_t* Qh_ = p.q + b * p.sq.b + hq * p.sq.h;
-        const bf16_t* dOh_ = p.dout + b * p.sdo.b + hq * p.sdo.h;
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sq.s + D) * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dOh_, 0, (int)(((int64_t)(p.Sq - 1) * p.sdo.s + D) * 2), 0x00020000);
-        char* base = smem + buf * BUFB;
-        const int lim = live ? p.Sq : 0;
-        Stage::issue(rq, base, t * BQ, lim, qs_s);
-        Stage::issue(rdo, base + TILE, t * BQ, lim, dos_s);
-        const int64_t srow = ((int64_t)b * p.Hq + hq) * p.Sq;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((w == 0 ? p.nlse : p.delta) + srow), 0, p.Sq * 4, 0x00020000);
-        char* sdst = w == 0 ? base + 2 * TILE : (w == 1 ? base + 2 * TILE + 256 : smem + DUMP + w * 256);  // wave-uniform
-        dma4(rs, sdst, (live && w < 2) ? (t * BQ + lane) * 4 : (int)0x80000000u);
-    };
+    auto stage = [&](int /*it*/, int buf) { stage_lean(buf); };
 
     // fragment addresses (bytes inside a tile of 128-byte rows): row reads: row r, chunk 2 ks + h; transposed reads: rows
     // 16 kk + 4 h + (i >> 2) (+8), chunk 4 cb + 2 ((lane >> 4) & 1) + ((i & 3) >> 1)
@@ -2595,10 +2586,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
             pin_loaded(Vf[ks]);
         }
         DmaTile<D, KB, 8>::issue(rk, smem + KIMG, n0, kvl, ks_s);
-        if constexpr (LEAN) {
-            sg = 0, stl = 0;
-            head_rsrc(0);
-        }
+        sg = 0, stl = 0;
+        head_rsrc(0);
         stage(0, 0);
         stage(1, 1);
         f32x16 dK[DT], dV[DT];
@@ -2613,38 +2602,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
             const int gq = it / nqt, t = it % nqt;
             return ((int64_t)b * p.Hq + hkv * G + gq) * nqt + t;
         };
-        auto scr_ptr = [&](int it) {  // this wave's 2 x 1 KiB of the tile's 16 KiB: [block w & 3][quad 2 kh + e][lane]
-            return scr + tile_id_of(it) * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
-        };
         // The running dQ of tile `it` travels scratch plane -> LDS by DMA one tile ahead (no VGPR-destination load in the
         // loop: beside hidden DMAs the compiler would wait vmcnt(0) for it and drain the ring).  Nothing to read in the
         // range's first key block or past the last tile: an out-of-range offset delivers zeros.
-        // LEAN: the tiles of a (batch, kv head) pair are consecutive in the plane (tile id = first tile of the pair + it): one
+        // the tiles of a (batch, kv head) pair are consecutive in the plane (tile id = first tile of the pair + it): one
         // descriptor over the pair's niter tiles, the tile number times 16 KiB in the lane offset; past the last tile the
         // offset is past the descriptor (zeros); in the range's first key block there is nothing to read (empty descriptor)
         float* const pair_scr = scr + tile_id_of(0) * (BQ * D);
-        const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, (first || (p.dbg & 1)) ? 0 : niter * (BQ * D * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, (first || (dbg & 1)) ? 0 : niter * (BQ * D * 4), 0x00020000);
         const int old_lane = ((w & 3) * 1024 + (2 * kh) * 256 + lane * 4) * 4;
         auto old_dma = [&](int it) {
-            if constexpr (LEAN) {
-                const int voff = old_lane + it * (BQ * D * 4);
-                dma16_nt(rpl, smem + OLD + w * 2048, voff);
-                dma16_nt(rpl, smem + OLD + w * 2048 + 1024, voff + 1024);
-                return;
-            }
-            const bool live = !first && it < niter;
-            const float* tb = scr + tile_id_of(live ? it : 0) * (BQ * D);
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)tb, 0, BQ * D * 4, 0x00020000);
-            const int voff = live ? ((w & 3) * 1024 + (2 * kh) * 256 + lane * 4) * 4 : (int)0x80000000u;
-            dma16_nt(ro, smem + OLD + w * 2048, voff);
-            dma16_nt(ro, smem + OLD + w * 2048 + 1024, live ? voff + 1024 : voff);
+            const int voff = old_lane + it * (BQ * D * 4);
+            dma16_nt(rpl, smem + OLD + w * 2048, voff);
+            dma16_nt(rpl, smem + OLD + w * 2048 + 1024, voff + 1024);
         };
         old_dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
         int buf = 0;
-        int cg = 0, ct = 0;  // LEAN: (query head of the kv group, query tile) of the tile being computed
+        int cg = 0, ct = 0;  // (query head of the kv group, query tile) of the tile being computed
         for (int it = 0; it < niter; ++it) {
             const char* Qs = smem + buf * BUFB;
             const char* dOs = Qs + TILE;
@@ -2706,21 +2683,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {  // V
-                    float pv = __builtin_amdgcn_exp2f(S[i] * sc);
-                    if constexpr (!LEAN) {
-                        if (!kval) pv = 0.f;
-                    }
+                    const float pv = __builtin_amdgcn_exp2f(S[i] * sc);
                     S[i] = pv;
                     dP[i] = pv * dP[i];
                 }
-                if constexpr (LEAN) {
-                    if (ragged) {  // block-uniform: only the last key block of a masked / non-multiple key range has keys to drop
-                        asm volatile("; ragged key block" ::: "memory");  // (keeps hipcc from if-converting the branch back into 64 selects per tile)
+                if (ragged) {  // block-uniform: only the last key block of a masked / non-multiple key range has keys to drop
+                    asm volatile("; ragged key block" ::: "memory");  // (keeps hipcc from if-converting the branch back into 64 selects per tile)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            S[i] = kval ? S[i] : 0.f;
-                            dP[i] = kval ? dP[i] : 0.f;
-                        }
+                    for (int i = 0; i < 16; ++i) {
+                        S[i] = kval ? S[i] : 0.f;
+                        dP[i] = kval ? dP[i] : 0.f;
                     }
                 }
                 bf16x8 Pf[2], dSf[2];
@@ -2767,7 +2739,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 }
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    if (LEAN && (p.dbg & 2) && kk >= 1) break;
+                    if ((dbg & 2) && kk >= 1) break;
                     const bf16x8 a_ = ka[kk % QF], b_ = sa[kk % QF];
                     if (kk + QF < 8) {
                         ka[kk % QF] = trfrag(kim + (kk + QF) * 16 * RB, dtw);
@@ -2802,13 +2774,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 sum0 = f32x4{acc[8], acc[9], acc[10], acc[11]} + p0 + o0;
                 sum1 = f32x4{acc[12], acc[13], acc[14], acc[15]} + p1 + o1;
             }
-            int gq, t;
-            if constexpr (LEAN) {
-                gq = cg, t = ct;
-                if (++ct == nqt) ct = 0, ++cg;
-            } else {
-                gq = it / nqt, t = it % nqt;
-            }
+            const int gq = cg, t = ct;
+            if (++ct == nqt) ct = 0, ++cg;
             if (final_store) {
                 const int q = t * BQ + qtw * 32 + r;
                 if (q < p.Sq) {
@@ -2817,16 +2784,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                     store4(dst, sum0[0] * s_, sum0[1] * s_, sum0[2] * s_, sum0[3] * s_);
                     store4(dst + 8, sum1[0] * s_, sum1[1] * s_, sum1[2] * s_, sum1[3] * s_);
                 }
-            } else if constexpr (LEAN) {
+            } else {
                 float* s0 = pair_scr + (int64_t)it * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
-                if (!(p.dbg & 1)) {
+                if (!(dbg & 1)) {
                     *reinterpret_cast<f32x4*>(s0) = sum0;
                     *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
                 }
-            } else {
-                float* s0 = scr_ptr(it);
-                *reinterpret_cast<f32x4*>(s0) = sum0;
-                *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
             }
             old_dma(it + 1);  // (the reads of this tile's copy above are complete: their values went into the sums)
             buf = buf == NB - 1 ? 0 : buf + 1;
@@ -2963,7 +2926,7 @@ __host__ inline int dkdv_nsplit(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
 // slice; the chip holds 256 workgroups: fewest rounds x passes wins, ties go to fewer slices (no reduce pass at 1).
 __host__ inline int bwd1_slices(int B, int Hq, int Hkv, int Sq, int Sk, int D) {
     (void)Hq, (void)Sq;
-    if (D != 64 || Sk <= 128 || (g_attn_variant != 0 && g_attn_variant != 5)) return 0;
+    if (D != 64 || Sk <= 128 || g_attn_variant != 0) return 0;
     const int64_t bhk = (int64_t)B * Hkv, nkb = (Sk + 255) / 256;
     // time ~ rounds of the 256 resident workgroups x key-block passes per workgroup.  Slicing (ns > 1) costs one fp32 plane
     // per slice and a reduce pass over all of them (measured: 16 planes of 252 MB = 0.7 ms beside a 3 ms kernel), so it
@@ -2991,21 +2954,19 @@ int launch_bwd1(AttnParams p, hipStream_t st) {
     constexpr size_t lds = 3 * (2 * 64 * D * 2 + 512) + 256 * D * 2 + 256 * 128 + 8 * 2048 + 8 * 256 + 8 * 2048;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd1_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int64_t rows = (int64_t)p.B * p.Hq * p.Sq * (D / 8);
     hipLaunchKernelGGL(attn_delta_kernel<D>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
     VFT_CHECK_LAUNCH("vft_attn_bwd(delta)");
+#ifdef VFT_ATTN_PROBE
     {
         const char* e = getenv("VFT_ATTN_DEBUG");
         p.dbg = e ? atoi(e) : 0;
     }
-    if (g_attn_variant == 5)  // A/B: the round-3/4 per-tile bookkeeping
-        hipLaunchKernelGGL((attn_bwd1_kernel<D, false>), dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
-    else
-        hipLaunchKernelGGL((attn_bwd1_kernel<D, true>), dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
+#endif
+    hipLaunchKernelGGL(attn_bwd1_kernel<D>, dim3((unsigned)(p.B * p.Hkv * p.nsplit)), dim3(512), lds, st, p);
     VFT_CHECK_LAUNCH("vft_attn_bwd(one pass)");
     if (p.nsplit > 1) {
         const int64_t n = bwd1_plane_floats(p.B, p.Hq, p.Sq, D) / 4;
@@ -3251,7 +3212,7 @@ extern "C" int vft_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 extern "C" int vft_attn_variant(int variant) {
-    VFT_CHECK_ARG((variant >= 0 && variant <= 3) || variant == 5, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels), 2 (8-wave dK/dV), 3 (dq + dkdv pair where the one-pass backward would run) or 5 (one-pass backward with the round-4 bookkeeping)", variant);
+    VFT_CHECK_ARG(variant >= 0 && variant <= 3, "vft_attn_variant: %d is not 0 (automatic), 1 (first-generation 4-wave kernels), 2 (8-wave dK/dV) or 3 (dq + dkdv pair where the one-pass backward would run)", variant);
     g_attn_variant = variant;
     return 0;
 }
