@@ -133,6 +133,26 @@ int vft_lora_wgrad2g_defer(const void* x, const void* u, const void* dy, const v
                            void* table, int slot, void* stream);
 int vft_lora_wgrad_reduce_many(const void* table, int n, int64_t max_elements, void* stream);
 
+/* Round 5 — the backward pass of LoRALinear (peft/lora.py:92-104 differentiated) with dy and x read ONCE each for the
+ * rank-sized work:
+ *   vft_lora_bwd_dy: the pass over dy[M,N] yields BOTH d(lora_up) = scale_w * dy^T t (partial sums + reduction exactly as
+ *                    vft_lora_wgrad2g / _defer do for that half; table == NULL: reduced at once) AND
+ *                    u_out[M,r] (bf16) = scale_u * dy . lora_up — the operand the data gradient's rank extension needs
+ *                    (vft_linear_fwd on the transposed weight, ext_x = u) — through per-column-tile partial sums in u_part
+ *                    (vft_lora_u_part_floats(M, N, r) floats) added in tile order (deterministic).  up_t = lora_up^T (r,N),
+ *                    r the padded rank (4 / 8 / 16).  Replaces vft_lora_down(dy, up_t): one full read of dy per layer.
+ *   vft_lora_bwd_x:  d(lora_down) = scale_w * u^T x, the other half of vft_lora_wgrad2g.
+ * Workspaces: vft_lora_bwd_workspace(M, N or K, r) bytes each; groups / rsub / accumulate / table / slot as above (ONE
+ * table entry per call). */
+int64_t vft_lora_u_part_floats(int M, int N, int r);
+size_t vft_lora_bwd_workspace(int M, int cols, int r);
+int vft_lora_bwd_dy(const void* dy, const void* t, const void* up_t, void* u_out, float* u_part, void* const* d_up,
+                    int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes, int M, int N, int r,
+                    int64_t lddy, float scale_u, float scale_w, void* table, int slot, void* stream);
+int vft_lora_bwd_x(const void* x, const void* u, void* const* d_down, int groups, int rsub, int accumulate,
+                   float* workspace, size_t ws_bytes, int M, int K, int r, int64_t ldx, float scale_w, void* table,
+                   int slot, void* stream);
+
 /* All derived adapter operands of a model in one launch.  `table` (device memory) holds n descriptors of seven int64:
  * {src0, src1, src2, dst, kind | groups << 32, r | rp << 32, L}; kind 0: dst (rp,L) = the groups' lora_down (r,L) stacked
  * and zero-padded to rp rows; kind 1: its transpose (L,rp); kind 2: dst (groups*L, rp) = blockdiag of the groups'

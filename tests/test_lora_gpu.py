@@ -152,6 +152,55 @@ def test_lora_conv2d_matches_reference_golden(gpu, tag):
         assert rel_err(layer(x.detach()).float().cpu(), G[f"{tag}.y_disabled"]) < 1e-2
 
 
+@pytest.mark.parametrize("M,K,N,r,rp,G", [(5000, 640, 1920, 4, 16, 3), (98304 // 8, 640, 5120, 4, 4, 1), (333, 1280, 1280, 8, 8, 1),
+                                          (26160 // 4, 3072, 8192, 16, 16, 1), (777, 192, 320, 4, 4, 1)])
+def test_lora_backward_reads_dy_once(gpu, M, K, N, r, rp, G):
+    """Round 5: u = s dy B comes out of the weight-gradient pass over dy (vft_lora_bwd_dy) and d(lora_down) out of a pass over x
+    (vft_lora_bwd_x) — against the two-kernel form of rounds 2-4 (vft_lora_down(dy) + vft_lora_wgrad2g) on the same operands:
+    u equal up to its bf16 rounding, every adapter gradient equal up to the order of the fp32 partial sums; fp32 reference for
+    both; twice, bit-identical (ordered sums, no atomics).  G = 3: the block-diagonal form of a fused q|k|v."""
+    from vision_ft_amd import kernels
+
+    g = torch.Generator().manual_seed(M + r)
+    bf = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(torch.bfloat16)  # noqa: E731
+    s = 0.5
+    x, dy = bf(M, K).to(gpu), bf(M, N).to(gpu)
+    As = [bf(r, K, sc=K**-0.5).to(gpu) for _ in range(G)]
+    Bs = [bf(N // G, r, sc=0.3).to(gpu) for _ in range(G)]
+    A_cat = torch.zeros(rp, K, dtype=torch.bfloat16, device=gpu)
+    Bt = torch.zeros(rp, N, dtype=torch.bfloat16, device=gpu)
+    for i in range(G):
+        A_cat[i * r:(i + 1) * r] = As[i]
+        Bt[i * r:(i + 1) * r, i * (N // G):(i + 1) * (N // G)] = Bs[i].t()
+    t = kernels.lora_down(x, A_cat, s)
+    params = list(zip(As, Bs))
+
+    def run(one_read: bool):
+        old = kernels.LORA_BWD_ONE_READ
+        kernels.LORA_BWD_ONE_READ = one_read
+        try:
+            u, grads = kernels._lora_bwd_rank(x, dy, t, Bt, params, r, rp, s)
+            kernels.flush_deferred_wgrads()
+        finally:
+            kernels.LORA_BWD_ONE_READ = old
+        torch.cuda.synchronize()
+        return u, grads
+
+    u1, g1 = run(True)
+    u0, g0 = run(False)
+    u1b, g1b = run(True)
+    u_ref = s * (dy.float() @ Bt.float().t())
+    assert rel_err(u1.float(), u_ref) < 6e-3 and rel_err(u0.float(), u_ref) < 6e-3
+    assert torch.equal(u1, u1b)
+    for i in range(G):
+        dA_ref = (u_ref[:, i * r:(i + 1) * r].t() @ x.float())
+        dB_ref = dy.float()[:, i * (N // G):(i + 1) * (N // G)].t() @ t.float()[:, i * r:(i + 1) * r]
+        for got, old_, again, ref in ((g1[2 * i], g0[2 * i], g1b[2 * i], dA_ref), (g1[2 * i + 1], g0[2 * i + 1], g1b[2 * i + 1], dB_ref)):
+            assert rel_err(got.float(), ref) < 1.2e-2, rel_err(got.float(), ref)
+            assert rel_err(got.float(), old_.float()) < 8e-3
+            assert torch.equal(got, again)
+
+
 def test_lora_wgrad_deterministic(gpu):
     from vision_ft_amd import kernels
 

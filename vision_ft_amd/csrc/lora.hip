@@ -314,19 +314,27 @@ struct ReduceDesc {
     float scale;
 };
 
+// Round 5 — the data gradient's low-rank activations u = s * dy * B ride in the pass over dy (`up_t` / `u_part` non-null, the
+// problem with X = dy): the workgroup's 64 x 128 slab of dy is in LDS anyway, so four v_mfma_f32_16x16x32_bf16 per wave and
+// slab give its contribution to u for those 64 rows from these 128 columns — u_part[column tile][row][rank] (fp32), summed
+// over the column tiles in order by lora_u_reduce_kernel.  That replaces vft_lora_down(dy): one full read of dy per adapted
+// layer and backward pass (the FeedForward up-projection's dy is 1 GB at the SDXL headline shape) for a partial-sum round
+// trip of 6 % of it at rank 4.
 __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r,
                                                                  int rows_per_block, ReduceDesc* slot, int nmb_total,
-                                                                 float scale, int accumulate) {
+                                                                 float scale, int accumulate, int zoff,
+                                                                 const bf16_t* __restrict__ up_t, float* __restrict__ u_part) {
+    const int pz = blockIdx.z + zoff;  // which problem: 0 (X = x, T = u -> d lora_down) or 1 (X = dy, T = t -> d lora_up)
     if (slot != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         ReduceDesc d;
-        d.p = blockIdx.z == 0 ? p0 : p1;
+        d.p = pz == 0 ? p0 : p1;
         d.nmb = nmb_total, d.r = r, d.accumulate = accumulate, d.scale = scale;
         slot[blockIdx.z] = d;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);                 // [64][WG_LD]
     bf16_t* Ts = reinterpret_cast<bf16_t*>(smem + 64 * WG_LD * 2);  // [64][r]
-    const WgradProblem& p = blockIdx.z == 0 ? p0 : p1;
+    const WgradProblem& p = pz == 0 ? p0 : p1;
     const int K = p.K;
     const int k0 = blockIdx.x * WG_COLS;
     if (k0 >= K) return;  // block-uniform
@@ -342,6 +350,18 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // u path (problem 1 only): this lane's lora_up^T fragments for the tile's four 32-column k-steps — A operand of the
+    // 16x16x32 MFMA: rank row lane & 15, columns k0 + 32 ks + 8 (lane >> 4) .. + 7 (rows >= r and columns >= K: zeros)
+    const bool with_u = pz == 1 && u_part != nullptr;
+    bf16x8 upf[4];
+    if (with_u) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int col = k0 + ks * 32 + 8 * (lane >> 4);
+            upf[ks] = zero8();
+            if ((lane & 15) < r && col < K) upf[ks] = *reinterpret_cast<const bf16x8*>(up_t + (int64_t)(lane & 15) * K + col);
+        }
+    }
     u32x4 xr[4];
     bf16x8 tr8 = zero8();
     auto fetch = [&](int r0) {
@@ -386,6 +406,18 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0
             bf16x8 a = tr_frag(Xs, WG_LD, ks * 16, wv * 32, lane);
             acc = mfma32(a, b, acc);
         }
+        if (with_u) {
+            // u_part[column tile][row][rank]: wave wv takes slab rows 16 wv .. + 15 (the MFMA's n), all 128 columns (k);
+            // D[m = 4 (lane >> 4) + i][n = lane & 15]: a lane holds four consecutive rank entries of one token row
+            f32x4 ua = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(Xs + (wv * 16 + (lane & 15)) * WG_LD + ks * 32 + 8 * (lane >> 4));
+                ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(upf[ks], xb, ua, 0, 0, 0);
+            }
+            const int row = r0 + wv * 16 + (lane & 15), jq = 4 * (lane >> 4);
+            if (row < mend && jq < r) *reinterpret_cast<f32x4*>(u_part + ((int64_t)blockIdx.x * M + row) * r + jq) = ua;
+        }
     }
     if (j < r) {
 #pragma unroll
@@ -420,6 +452,20 @@ __global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(WgradProblem p0,
     v *= s;
     if (accumulate) v += (float)*dst;
     *dst = (bf16_t)v;
+}
+
+// u[M][r] (bf16) = s * sum over column tiles c (in order) of u_part[c][M][r]; one thread = four rank entries of a row
+__global__ __launch_bounds__(256) void lora_u_reduce_kernel(const float* __restrict__ u_part, bf16_t* __restrict__ u, int64_t M,
+                                                            int r, int ctiles, float s) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // float4 index
+    const int64_t n4 = M * r / 4;
+    if (e >= n4) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < ctiles; ++c) v += reinterpret_cast<const f32x4*>(u_part)[(int64_t)c * n4 + e];
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(v[i] * s);
+    reinterpret_cast<bf16x4*>(u)[e] = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,35 +632,48 @@ extern "C" size_t vft_lora_wgrad_workspace(int M, int K, int N, int r) {
     return (size_t)((M + rpb - 1) / rpb) * (size_t)(K + N) * (size_t)r * sizeof(float);
 }
 
+// which: 3 = both problems in one launch (the forms of rounds 1-4); 1 = only d(lora_down) = u^T x; 2 = only d(lora_up) = dy^T t,
+// optionally with the u partial sums (up_t, u_part: see the kernel).  The workspace of a one-problem launch holds that
+// problem's partial sums only.
 static int wgrad_launch(const void* x, const void* u, const void* dy, const void* t, void* const* d_down, void* const* d_up,
                         int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes, int M, int K, int N, int r,
-                        int64_t ldx, int64_t lddy, float scale, void* stream, const char* name, void* defer_slot = nullptr) {
-    if (chk(x && u && dy && t && d_down && d_up && workspace, "vft_lora_wgrad2: null pointer")) return 1;
+                        int64_t ldx, int64_t lddy, float scale, void* stream, const char* name, void* defer_slot = nullptr,
+                        int which = 3, const void* up_t = nullptr, float* u_part = nullptr) {
+    if (chk(((which & 1) ? (x && u && d_down) : true) && ((which & 2) ? (dy && t && d_up) : true) && workspace, "vft_lora_wgrad2: null pointer")) return 1;
     VFT_CHECK_ARG(M > 0 && K > 0 && N > 0 && r > 0 && r <= 32, "%s: need M,K,N>0 and 0<r<=32", name);
     VFT_CHECK_ARG(K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, "%s: K, N, strides must be multiples of 8", name);
-    VFT_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "%s: activations must be 16-byte aligned", name);
+    VFT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy) & 15) == 0, "%s: activations must be 16-byte aligned", name);
     VFT_CHECK_ARG(groups >= 1 && groups <= 3 && rsub >= 1 && groups * rsub <= r && N % groups == 0,
                   "%s: need 1 <= groups <= 3, groups * rsub <= r and N %% groups == 0 (groups=%d rsub=%d r=%d N=%d)", name, groups, rsub, r, N);
-    VFT_CHECK_ARG(ws_bytes >= vft_lora_wgrad_workspace(M, K, N, r), "%s: workspace too small", name);
-    const int rpb = wgrad_rows_per_block(M, K, N);
+    VFT_CHECK_ARG(which >= 1 && which <= 3, "%s: which = %d", name, which);
+    VFT_CHECK_ARG((up_t == nullptr) == (u_part == nullptr) && (up_t == nullptr || (which == 2 && r % 4 == 0 && r <= 16 && (((uintptr_t)up_t | (uintptr_t)u_part) & 15) == 0)),
+                  "%s: the u partial sums need the dy-only launch, a rank padded to 4 / 8 / 16 and 16-byte aligned up_t / u_part", name);
+    const int rpb = wgrad_rows_per_block(M, (which & 1) ? K : 0, (which & 2) ? N : 0);
     const int nmb = (M + rpb - 1) / rpb;
+    const size_t need = (size_t)nmb * ((which & 1 ? (size_t)K : 0) + (which & 2 ? (size_t)N : 0)) * (size_t)r * sizeof(float);
+    VFT_CHECK_ARG(ws_bytes >= need, "%s: workspace too small (%zu < %zu bytes)", name, ws_bytes, need);
     WgradProblem pa{(const bf16_t*)x, (const bf16_t*)u, workspace, {nullptr, nullptr, nullptr}, K, ldx, 0, groups, rsub, 0};
-    WgradProblem pb{(const bf16_t*)dy, (const bf16_t*)t, workspace + (size_t)nmb * K * r, {nullptr, nullptr, nullptr}, N, lddy,
+    WgradProblem pb{(const bf16_t*)dy, (const bf16_t*)t, workspace + ((which & 1) ? (size_t)nmb * K * r : 0), {nullptr, nullptr, nullptr}, N, lddy,
                     1, groups, rsub, N / groups};
     for (int g = 0; g < groups; ++g) {
-        if (chk(d_down[g] && d_up[g], "vft_lora_wgrad2: null gradient pointer")) return 1;
-        pa.out[g] = (bf16_t*)d_down[g];
-        pb.out[g] = (bf16_t*)d_up[g];
+        if (chk(((which & 1) ? d_down[g] != nullptr : true) && ((which & 2) ? d_up[g] != nullptr : true), "vft_lora_wgrad2: null gradient pointer")) return 1;
+        if (which & 1) pa.out[g] = (bf16_t*)d_down[g];
+        if (which & 2) pb.out[g] = (bf16_t*)d_up[g];
     }
     const size_t lds = 64 * WG_LD * 2 + 64 * (size_t)r * 2;
-    const int kmax = K > N ? K : N;
-    hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, 2), dim3(256), lds,
-                       (hipStream_t)stream, pa, pb, M, r, rpb, (ReduceDesc*)defer_slot, nmb, scale, accumulate);
+    const int kmax = which == 3 ? (K > N ? K : N) : (which == 1 ? K : N);
+    hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, which == 3 ? 2 : 1), dim3(256), lds,
+                       (hipStream_t)stream, pa, pb, M, r, rpb, (ReduceDesc*)defer_slot, nmb, scale, accumulate, which == 2 ? 1 : 0,
+                       (const bf16_t*)up_t, u_part);
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(partial)");
     if (defer_slot != nullptr) return 0;  // the reduction is queued: vft_lora_wgrad_reduce_many runs it
     const int64_t ne = (int64_t)kmax * r;
-    hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 2), dim3(256), 0,
-                       (hipStream_t)stream, pa, pb, nmb, r, scale, accumulate);
+    if (which == 3)
+        hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 2), dim3(256), 0,
+                           (hipStream_t)stream, pa, pb, nmb, r, scale, accumulate);
+    else  // one problem: it sits in slot 0 of the reduce kernel's pair
+        hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((unsigned)((ne + 255) / 256), 1), dim3(256), 0,
+                           (hipStream_t)stream, which == 1 ? pa : pb, pb, nmb, r, scale, accumulate);
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(reduce)");
     return 0;
 }
@@ -661,6 +720,44 @@ extern "C" int vft_lora_wgrad2g_defer(const void* x, const void* u, const void* 
     if (chk(table != nullptr && slot >= 0, "vft_lora_wgrad2g_defer: null table / negative slot")) return 1;
     return wgrad_launch(x, u, dy, t, d_down, d_up, groups, rsub, accumulate, workspace, ws_bytes, M, K, N, r, ldx, lddy, scale,
                         stream, "vft_lora_wgrad2g_defer", (char*)table + (size_t)slot * sizeof(ReduceDesc));
+}
+
+// ---- round 5: the backward's rank-sized work in two passes that read dy and x ONCE each ------------------------------------
+// vft_lora_bwd_dy:  d(lora_up) partial sums (as vft_lora_wgrad2g[_defer], problem "dy^T t" only) AND u = scale_u * dy * lora_up
+//                   (M, r) bf16 — the operand the data-gradient GEMM's rank extension needs — from the same pass over dy:
+//                   per column tile partial sums in u_part (ctiles * M * r floats, ctiles = ceil(N / 128): vft_lora_u_part_floats),
+//                   then an ordered sum.  Replaces vft_lora_down(dy, lora_up^T) + half of vft_lora_wgrad2g.
+// vft_lora_bwd_x:   d(lora_down) partial sums (problem "u^T x" only) — the other half.
+// table / slot: as vft_lora_wgrad2g_defer (one descriptor per call), or table == nullptr for an immediate reduction.
+extern "C" int64_t vft_lora_u_part_floats(int M, int N, int r) { return (int64_t)((N + WG_COLS - 1) / WG_COLS) * M * r; }
+// bytes of partial sums of ONE of the two problems (cols = N for vft_lora_bwd_dy, K for vft_lora_bwd_x)
+extern "C" size_t vft_lora_bwd_workspace(int M, int cols, int r) {
+    const int rpb = wgrad_rows_per_block(M, cols, 0);
+    return (size_t)((M + rpb - 1) / rpb) * (size_t)cols * (size_t)r * sizeof(float);
+}
+
+extern "C" int vft_lora_bwd_dy(const void* dy, const void* t, const void* up_t, void* u_out, float* u_part, void* const* d_up,
+                               int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes, int M, int N, int r,
+                               int64_t lddy, float scale_u, float scale_w, void* table, int slot, void* stream) {
+    if (chk(up_t && u_out && u_part, "vft_lora_bwd_dy: null pointer")) return 1;
+    VFT_CHECK_ARG(((uintptr_t)u_out & 7) == 0, "vft_lora_bwd_dy: u_out must be 8-byte aligned");
+    void* none[3] = {nullptr, nullptr, nullptr};
+    if (wgrad_launch(nullptr, nullptr, dy, t, none, d_up, groups, rsub, accumulate, workspace, ws_bytes, M, /*K=*/8, N, r, 8, lddy, scale_w,
+                     stream, "vft_lora_bwd_dy", table ? (char*)table + (size_t)slot * sizeof(ReduceDesc) : nullptr, 2, up_t, u_part))
+        return 1;
+    const int64_t n4 = (int64_t)M * r / 4;
+    hipLaunchKernelGGL(lora_u_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u_part,
+                       (bf16_t*)u_out, (int64_t)M, r, (N + WG_COLS - 1) / WG_COLS, scale_u);
+    VFT_CHECK_LAUNCH("vft_lora_bwd_dy(u reduce)");
+    return 0;
+}
+
+extern "C" int vft_lora_bwd_x(const void* x, const void* u, void* const* d_down, int groups, int rsub, int accumulate,
+                              float* workspace, size_t ws_bytes, int M, int K, int r, int64_t ldx, float scale_w, void* table,
+                              int slot, void* stream) {
+    void* none[3] = {nullptr, nullptr, nullptr};
+    return wgrad_launch(x, u, nullptr, nullptr, d_down, none, groups, rsub, accumulate, workspace, ws_bytes, M, K, /*N=*/8 * groups, r, ldx, 8,
+                        scale_w, stream, "vft_lora_bwd_x", table ? (char*)table + (size_t)slot * sizeof(ReduceDesc) : nullptr, 1);
 }
 
 // n entries of the table, the widest of which has max_elements = K * r output elements

@@ -831,6 +831,68 @@ def _lora_wgrad_into(x2, u, dy2, t, params, r: int, rp: int, s: float):
     return [g for pair in targets for g in pair]
 
 
+# Round 5: the backward's u = s dy B comes out of the weight-gradient pass over dy instead of its own pass (vft_lora_bwd_dy /
+# vft_lora_bwd_x: dy and x are read once each for the rank-sized work).  A/B switch; also the path when adapters are frozen.
+LORA_BWD_ONE_READ = os.environ.get("VFT_LORA_BWD_ONE_READ", "1") != "0"
+
+
+def _lora_bwd_rank(x2, dy2, t, Bt, params, r: int, rp: int, s: float):
+    """(u, grads) of one LoRA-adapted projection call (or a fused group of up to three that share x2): u (M, rp) = s dy B for
+    the data gradient's rank extension, grads as `_lora_wgrad_into` returns them.  `Bt` = lora_up transposed, rank-padded
+    (rp, N) (block-diagonal for a group).  One pass over dy gives u and d(lora_up), one pass over x gives d(lora_down)."""
+    G = len(params)
+    M, K = x2.shape
+    N = dy2.shape[1]
+    targets = [(_grad_target(a), _grad_target(b)) for a, b in params]
+    inplace = all(ga is not None and gb is not None for ga, gb in targets)
+    if not (LORA_BWD_ONE_READ and rp in (4, 8, 16) and Bt.is_contiguous() and Bt.dtype == torch.bfloat16 and dy2.stride(1) == 1):
+        u = lora_down(dy2, Bt, s)
+        return u, _lora_wgrad_into(x2, u, dy2, t, params, r, rp, 1.0)
+    PACK_STATS["grad_in_place" if inplace else "grad_returned"] += G
+    if not inplace:
+        targets = [(torch.empty((r, K), dtype=torch.bfloat16, device=x2.device),
+                    torch.empty((N // G, r), dtype=torch.bfloat16, device=x2.device)) for _ in range(G)]
+    lib = _C.lib()
+    dd = (ctypes.c_void_p * 3)(*[t_[0].data_ptr() for t_ in targets])
+    du = (ctypes.c_void_p * 3)(*[t_[1].data_ptr() for t_ in targets])
+    u = torch.empty((M, rp), dtype=torch.bfloat16, device=x2.device)
+    u_part = torch.empty(int(lib.vft_lora_u_part_floats(M, N, rp)), dtype=torch.float32, device=x2.device)
+    nb_dy, nb_x = int(lib.vft_lora_bwd_workspace(M, N, rp)), int(lib.vft_lora_bwd_workspace(M, K, rp))
+    q = table = None
+    ws_dy = ws_x = None
+    if inplace and DEFER_WGRAD_REDUCE:
+        q = _WgradQueue.get(x2.device)
+        q.claim(targets)
+        ws_dy = q.take(max(nb_dy // 4, 1))
+        ws_x = q.take(max(nb_x // 4, 1)) if ws_dy is not None else None
+        if ws_x is None:
+            q = None
+    if q is None:
+        ws_dy = torch.empty(max(nb_dy // 4, 1), dtype=torch.float32, device=x2.device)
+        ws_x = torch.empty(max(nb_x // 4, 1), dtype=torch.float32, device=x2.device)
+    acc = 1 if inplace else 0
+    with _Timed("lora_wgrad2", 2.0 * M * (K + N)):
+        st = lib.vft_lora_bwd_dy(_ptr(dy2), _ptr(t), _ptr(Bt), _ptr(u), _ptr(u_part), du, G, r, acc, _ptr(ws_dy), nb_dy, M, N, rp,
+                                 dy2.stride(0), float(s), 1.0, _ptr(q.table) if q is not None else None, q.count if q is not None else 0,
+                                 _stream())
+        _C.check(st, "vft_lora_bwd_dy")
+        st = lib.vft_lora_bwd_x(_ptr(x2), _ptr(u), dd, G, r, acc, _ptr(ws_x), nb_x, M, K, rp, x2.stride(0), 1.0,
+                                _ptr(q.table) if q is not None else None, (q.count + 1) if q is not None else 0, _stream())
+        _C.check(st, "vft_lora_bwd_x")
+    if q is not None:
+        q.count += 2
+        q.max_ne = max(q.max_ne, K * rp, N * rp)
+        if not q.callback_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(q.flush)
+                q.callback_queued = True
+            except RuntimeError:  # not inside a backward pass: nothing will call back
+                q.flush()
+    if inplace:
+        return u, [None] * (2 * G)
+    return u, [g for pair in targets for g in pair]
+
+
 class AdapterPack:
     """Operand forms of every LoRA adapter of a model that the fused projection GEMM consumes — lora_up transposed
     (for u = dy B), lora_down transposed (the data gradient's rank extension), the concatenated / block-diagonal /
@@ -1075,12 +1137,14 @@ class _LoRALinearFused(torch.autograd.Function):
         dy2 = _bf16_rows(dy)
         dx = dA = dB = None
         with torch.cuda.device(dy.device):
-            u = lora_down(dy2, Bt if Bt is not None else B_p.t().contiguous(), s)  # (M, rp) = s dy B
+            Bt_ = Bt if Bt is not None else B_p.t().contiguous()
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                u, (dA, dB) = _lora_bwd_rank(x2, dy2, t, Bt_, [ctx.params], r, A_p.shape[0], s)  # u = s dy B rides in the pass over dy
+            else:
+                u = lora_down(dy2, Bt_, s)  # (M, rp) = s dy B
             if ctx.needs_input_grad[0]:
                 dx2 = linear_fused(dy2, _transposed_weight(weight), None, ext_x=u, ext_w=At if At is not None else A_p.t().contiguous())
                 dx = dx2.view(ctx.xshape)
-            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-                dA, dB = _lora_wgrad_into(x2, u, dy2, t, [ctx.params], r, A_p.shape[0], 1.0)
         dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[6] else None
         return dx, None, None, dA, dB, None, dres, None
 
@@ -1129,12 +1193,14 @@ class _LoRASiblings(torch.autograd.Function):
                 if dys[i] is None:
                     continue
                 dy2 = _bf16_rows(dys[i])
-                u = lora_down(dy2, Bt if Bt is not None else B_p.t().contiguous(), s)
+                Bt_ = Bt if Bt is not None else B_p.t().contiguous()
+                if ctx.needs_input_grad[3 + 5 * i + 2] or ctx.needs_input_grad[3 + 5 * i + 3]:
+                    u, (grads[5 * i + 2], grads[5 * i + 3]) = _lora_bwd_rank(x2, dy2, t, Bt_, [params], r, A_p.shape[0], s)
+                else:
+                    u = lora_down(dy2, Bt_, s)
                 if ctx.needs_input_grad[0]:
                     dx2 = linear_fused(dy2, _transposed_weight(weight), None, residual=dx2, ext_x=u,
                                        ext_w=At if At is not None else A_p.t().contiguous())
-                if ctx.needs_input_grad[3 + 5 * i + 2] or ctx.needs_input_grad[3 + 5 * i + 3]:
-                    grads[5 * i + 2], grads[5 * i + 3] = _lora_wgrad_into(x2, u, dy2, t, [params], r, A_p.shape[0], 1.0)
         dx = dx2.view(ctx.xshape) if dx2 is not None else None
         return (dx, None, None, *grads)
 
@@ -1203,12 +1269,14 @@ class _LoRAGroupFused(torch.autograd.Function):
         grads = [None] * (2 * G)
         dx = None
         with torch.cuda.device(dy.device):
-            u = lora_down(dy, Bt if Bt is not None else B_blk.t().contiguous(), s)
+            Bt_ = Bt if Bt is not None else B_blk.t().contiguous()
+            if any(ctx.needs_input_grad[5:]):
+                u, grads = _lora_bwd_rank(x2, dy, t, Bt_, ctx.params, r, A_cat.shape[0], s)
+            else:
+                u = lora_down(dy, Bt_, s)
             if ctx.needs_input_grad[0]:
                 dx = linear_fused(dy, _transposed_weight(wcat), None, ext_x=u,
                                   ext_w=At if At is not None else A_cat.t().contiguous()).view(ctx.xshape)
-            if any(ctx.needs_input_grad[5:]):
-                grads = _lora_wgrad_into(x2, u, dy, t, ctx.params, r, A_cat.shape[0], 1.0)
         return (dx, None, None, None, None, *grads)
 
 
@@ -1270,13 +1338,15 @@ class _LoRAQKVFused(torch.autograd.Function):
             dy = torch.cat([g.permute(0, 2, 1, 3).reshape(M, N) for g in (dq, dk, dv)], dim=1).to(torch.bfloat16)
         grads = [None] * 6
         with torch.cuda.device(dy.device):
-            u = lora_down(dy, Bt if Bt is not None else B_blk.t().contiguous(), s)  # (M, rp) = s dy blockdiag(B)
+            Bt_ = Bt if Bt is not None else B_blk.t().contiguous()
+            if any(ctx.needs_input_grad[2:8]):
+                u, grads = _lora_bwd_rank(x2, dy, t, Bt_, ctx.params, r, A_cat.shape[0], s)  # u (M, rp) = s dy blockdiag(B)
+            else:
+                u = lora_down(dy, Bt_, s)
             dx = None
             if ctx.needs_input_grad[0]:
                 dx = linear_fused(dy, _transposed_weight(wqkv), None, ext_x=u,
                                   ext_w=At if At is not None else A_cat.t().contiguous()).view(ctx.xshape)
-            if any(ctx.needs_input_grad[2:8]):
-                grads = _lora_wgrad_into(x2, u, dy, t, ctx.params, r, A_cat.shape[0], 1.0)
         return (dx, None, *grads, None, None, None)
 
 
@@ -1392,12 +1462,14 @@ class _QLoRALinear(torch.autograd.Function):
         dy2 = _bf16_rows(dy)
         dx = dA = dB = None
         with torch.cuda.device(dy.device):
-            u = lora_down(dy2, Bt if Bt is not None else B.t().contiguous(), s)  # (M, r) = s dy . B
+            Bt_ = Bt if Bt is not None else B.t().contiguous()
+            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+                u, (dA, dB) = _lora_bwd_rank(x2, dy2, t, Bt_, [ctx.params], A.shape[0], A.shape[0], s)
+            else:
+                u = lora_down(dy2, Bt_, s)  # (M, r) = s dy . B
             if ctx.needs_input_grad[0]:
                 dx2 = _nf4_gemm(dy2, ctx.qstate, None, True, ext_x=u, ext_w=At if At is not None else A.t().contiguous())
                 dx = dx2.view(ctx.xshape)
-            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-                dA, dB = _lora_wgrad_into(x2, u, dy2, t, [ctx.params], A.shape[0], A.shape[0], 1.0)
         dres = dy.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[6] else None
         return dx, None, dA, dB, None, None, dres, None
 
