@@ -279,7 +279,7 @@ def family_table(prof: dict, steps: int) -> dict:
 
 
 def pmc_traffic(family: str):
-    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r03_d_pmc_hbm_traffic.csv, falling
+    """HBM bytes per launch of the family's kernel from the committed PMC passes (profiles/r05_a_pmc_hbm_traffic.csv, falling
     back to earlier files: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/pmc_run.py,
     gfx950 x2 fetch correction applied) — measured at the shape named in the note, not inside this run."""
     import csv
@@ -287,7 +287,7 @@ def pmc_traffic(family: str):
     want = {"linear_gemm": "lin8_kernel", "conv3x3": "lin8_conv", "attention_fwd": "attn_fwd3_kernel", "attention_bwd": "attn_bwd1_kernel", "gemm_nf4": "lin8_nf4",
             "weight_grad": "wg8_kernel<false>"}.get(family)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_b_pmc_hbm_traffic.csv", "r04_a_pmc_hbm_traffic.csv", "r03_d_pmc_hbm_traffic.csv", "r03_c_pmc_hbm_traffic.csv", "r03_b_pmc_hbm_traffic.csv", "r03_a_pmc_hbm_traffic.csv", "r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r05_a_pmc_hbm_traffic.csv", "r04_b_pmc_hbm_traffic.csv", "r04_a_pmc_hbm_traffic.csv", "r03_d_pmc_hbm_traffic.csv", "r03_c_pmc_hbm_traffic.csv", "r03_b_pmc_hbm_traffic.csv", "r03_a_pmc_hbm_traffic.csv", "r02_e_pmc_hbm_traffic.csv", "r02_c_pmc_hbm_traffic.csv", "r02_b_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         try:
             for row in csv.DictReader(open(os.path.join(root, name))):
                 if want and row["kernel"] == want:
