@@ -242,7 +242,10 @@ def test_graph_replay_takes_the_same_steps_as_eager(gpu, tmp_path, accum):
     noise = dist(u0, u0b)
     print(f"[determinism] eager-vs-eager weight distance {noise:.3e}, losses equal: {l0 == l0b}; graph-vs-eager {dist(u0, u1):.3e}")
     assert l0 == l0b and all(torch.equal(u0[k], u0b[k]) for k in u0), (noise, l0, l0b)
-    assert dist(u0, u1) < 0.12, (dist(u0, u1), noise)
+    # ... and the replayed run takes the SAME steps: both modes launch the same kernels (the optimizer too: capturable fused
+    # AdamW with a device-resident learning rate in either mode) on the same operands
+    assert dist(u0, u1) < 1e-3 or all(torch.equal(u0[k], u1[k]) for k in u0), (dist(u0, u1), noise)
+    print(f"[determinism] graph-vs-eager bitwise: {all(torch.equal(u0[k], u1[k]) for k in u0)}, losses equal: {l0 == l1}")
 
 
 def test_lumina2_trainer_replays_from_a_graph(gpu, tmp_path):

@@ -146,7 +146,10 @@ class Trainer:
         # gradient-norm clipping reduces over these buffers directly (ModelForTraining.after_backward)
         getattr(self, "raw_model", self.model)._flat_grad_buffers = list(self.dp.flat.buffers.values())
         args = dict(self.config.optimizer.args)
-        if self.config.trainer.hip_graph and torch.cuda.is_available() and _accepts_capturable(self.config.optimizer.name):
+        if torch.cuda.is_available() and _accepts_capturable(self.config.optimizer.name):
+            # the same optimizer kernel whether the step is replayed from HIP graphs or launched eagerly (`hip_graph: false`):
+            # with the step itself bit-reproducible (round 5) the two modes then take bit-identical steps — graph replay is an
+            # execution detail, not a numerical variant (tests/test_trainer_gpu.py)
             args.setdefault("capturable", True)
             if self.config.optimizer.name.rsplit(".", 1)[-1] in ("Adam", "AdamW", "SGD", "Adagrad"):
                 args.setdefault("fused", True)
