@@ -284,5 +284,7 @@ def test_lumina2_trainer_replays_from_a_graph(gpu, tmp_path):
         finally:
             Lumina2ForTextToImageTraining.static_layout = True
     assert len(runs["graph_static"]) == 2 * 4 and all(torch.isfinite(torch.tensor(runs["graph_static"])))
-    assert torch.allclose(torch.tensor(runs["eager_static"]), torch.tensor(runs["graph_static"]), rtol=2e-3, atol=1e-4), runs
+    # (round 5: eager and replayed runs launch the same kernels, the optimizer included — the losses are the same numbers)
+    print(f"[determinism] lumina2 eager_static == graph_static: {runs['eager_static'] == runs['graph_static']}")
+    assert runs["eager_static"] == runs["graph_static"], runs
     assert torch.allclose(torch.tensor(runs["eager_ragged"]), torch.tensor(runs["eager_static"]), rtol=5e-3, atol=1e-4), runs
