@@ -138,14 +138,14 @@ int vft_lora_wgrad_reduce_many(const void* table, int n, int64_t max_elements, v
  *   vft_lora_bwd_dy: the pass over dy[M,N] yields BOTH d(lora_up) = scale_w * dy^T t (partial sums + reduction exactly as
  *                    vft_lora_wgrad2g / _defer do for that half; table == NULL: reduced at once) AND
  *                    u_out[M,r] (bf16) = scale_u * dy . lora_up — the operand the data gradient's rank extension needs
- *                    (vft_linear_fwd on the transposed weight, ext_x = u) — through per-column-tile partial sums in u_part
+ *                    (vft_linear_fwd on the transposed weight, ext_x = u) — through per-512-column-strip partial sums in u_part
  *                    (vft_lora_u_part_floats(M, N, r) floats) added in tile order (deterministic).  up_t = lora_up^T (r,N),
  *                    r the padded rank (4 / 8 / 16).  Replaces vft_lora_down(dy, up_t): one full read of dy per layer.
  *   vft_lora_bwd_x:  d(lora_down) = scale_w * u^T x, the other half of vft_lora_wgrad2g.
  * Workspaces: vft_lora_bwd_workspace(M, N or K, r) bytes each; groups / rsub / accumulate / table / slot as above (ONE
  * table entry per call). */
 int64_t vft_lora_u_part_floats(int M, int N, int r);
-size_t vft_lora_bwd_workspace(int M, int cols, int r);
+size_t vft_lora_bwd_workspace(int M, int cols, int r, int with_u); /* with_u: 1 for the dy pass, 0 for the x pass */
 int vft_lora_bwd_dy(const void* dy, const void* t, const void* up_t, void* u_out, float* u_part, void* const* d_up,
                     int groups, int rsub, int accumulate, float* workspace, size_t ws_bytes, int M, int N, int r,
                     int64_t lddy, float scale_u, float scale_w, void* table, int slot, void* stream);

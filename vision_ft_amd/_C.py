@@ -52,7 +52,7 @@ SIGNATURES: dict[str, tuple] = {
     "vft_lora_wgrad2g_defer": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p, c_size_t] + [c_int] * 4 + [c_int64, c_int64, c_float, c_void_p, c_int, c_void_p]),
     "vft_lora_wgrad_reduce_many": (c_int, [c_void_p, c_int, c_int64, c_void_p]),
     "vft_lora_u_part_floats": (c_int64, [c_int, c_int, c_int]),
-    "vft_lora_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "vft_lora_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vft_lora_bwd_dy": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int64, c_float, c_float, c_void_p, c_int, c_void_p]),
     "vft_lora_bwd_x": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_int, c_void_p]),
     "vft_lora_pack": (c_int, [c_void_p, c_int, c_void_p]),

@@ -316,10 +316,14 @@ struct ReduceDesc {
 
 // Round 5 — the data gradient's low-rank activations u = s * dy * B ride in the pass over dy (`up_t` / `u_part` non-null, the
 // problem with X = dy): the workgroup's 64 x 128 slab of dy is in LDS anyway, so four v_mfma_f32_16x16x32_bf16 per wave and
-// slab give its contribution to u for those 64 rows from these 128 columns — u_part[column tile][row][rank] (fp32), summed
-// over the column tiles in order by lora_u_reduce_kernel.  That replaces vft_lora_down(dy): one full read of dy per adapted
+// slab give its contribution to u for those 64 rows from these 128 columns — u_part[512-column strip][row][rank] (fp32), summed
+// over the strips in order by lora_u_reduce_kernel.  That replaces vft_lora_down(dy): one full read of dy per adapted
 // layer and backward pass (the FeedForward up-projection's dy is 1 GB at the SDXL headline shape) for a partial-sum round
 // trip of 6 % of it at rank 4.
+// CT = column tiles (of 128) one workgroup walks per row slab: 1 (the form of rounds 1-4), or 4 for the pass over dy that also
+// produces u — its partial sums are then per 512-column STRIP: a quarter of the u_part round trip (at the padded rank 16 of a
+// fused q|k|v the per-tile form cost half of what the removed pass over dy had cost).
+template <int CT>
 __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r,
                                                                  int rows_per_block, ReduceDesc* slot, int nmb_total,
                                                                  float scale, int accumulate, int zoff,
@@ -336,8 +340,9 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0
     bf16_t* Ts = reinterpret_cast<bf16_t*>(smem + 64 * WG_LD * 2);  // [64][r]
     const WgradProblem& p = pz == 0 ? p0 : p1;
     const int K = p.K;
-    const int k0 = blockIdx.x * WG_COLS;
+    const int k0 = blockIdx.x * (CT * WG_COLS);
     if (k0 >= K) return;  // block-uniform
+    const int nct = min(CT, (K - k0 + WG_COLS - 1) / WG_COLS);  // column tiles of this strip that exist (block-uniform)
     const bf16_t* __restrict__ x = p.x;
     const bf16_t* __restrict__ t = p.t;
     const int64_t ldx = p.ldx;
@@ -346,85 +351,102 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0
     const int mstart = mb * rows_per_block;
     const int mend = min(M, mstart + rows_per_block);
     const int tvecs = 64 * r / 8;  // 16-byte vectors in one 64-row slab of T
-    f32x16 acc;
+    f32x16 acc[CT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[cc][i] = 0.f;
 
-    // u path (problem 1 only): this lane's lora_up^T fragments for the tile's four 32-column k-steps — A operand of the
-    // 16x16x32 MFMA: rank row lane & 15, columns k0 + 32 ks + 8 (lane >> 4) .. + 7 (rows >= r and columns >= K: zeros)
+    // u path (problem 1 only): this lane's lora_up^T fragments for every 32-column k-step of the strip — A operand of the
+    // 16x16x32 MFMA: rank row lane & 15, columns k0 + 128 cc + 32 ks + 8 (lane >> 4) .. + 7 (rows >= r, columns >= K: zeros)
     const bool with_u = pz == 1 && u_part != nullptr;
-    bf16x8 upf[4];
+    bf16x8 upf[CT][4];
     if (with_u) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int col = k0 + ks * 32 + 8 * (lane >> 4);
-            upf[ks] = zero8();
-            if ((lane & 15) < r && col < K) upf[ks] = *reinterpret_cast<const bf16x8*>(up_t + (int64_t)(lane & 15) * K + col);
-        }
+        for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int col = k0 + cc * WG_COLS + ks * 32 + 8 * (lane >> 4);
+                upf[cc][ks] = zero8();
+                if ((lane & 15) < r && col < K) upf[cc][ks] = *reinterpret_cast<const bf16x8*>(up_t + (int64_t)(lane & 15) * K + col);
+            }
     }
     u32x4 xr[4];
     bf16x8 tr8 = zero8();
-    auto fetch = [&](int r0) {
+    auto fetch = [&](int r0, int cc) {  // the X tile of (slab r0, column tile cc); with cc == 0 also the slab's rows of T
+        const int kc = k0 + cc * WG_COLS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = q * 256 + tid;
             const int row = c / 16, col = (c % 16) * 8;
             xr[q] = u32x4{0u, 0u, 0u, 0u};
-            if (r0 + row < mend && k0 + col < K) xr[q] = *reinterpret_cast<const u32x4*>(x + (int64_t)(r0 + row) * ldx + k0 + col);
+            if (r0 + row < mend && kc + col < K) xr[q] = *reinterpret_cast<const u32x4*>(x + (int64_t)(r0 + row) * ldx + kc + col);
         }
-        tr8 = zero8();
-        if (tid < tvecs) {
-            const int64_t e0 = (int64_t)r0 * r + tid * 8;
-            if (e0 + 8 <= (int64_t)mend * r) {
-                tr8 = *reinterpret_cast<const bf16x8*>(t + e0);
-            } else {
+        if (cc == 0) {
+            tr8 = zero8();
+            if (tid < tvecs) {
+                const int64_t e0 = (int64_t)r0 * r + tid * 8;
+                if (e0 + 8 <= (int64_t)mend * r) {
+                    tr8 = *reinterpret_cast<const bf16x8*>(t + e0);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (e0 + q < (int64_t)mend * r) tr8[q] = t[e0 + q];
+                    for (int q = 0; q < 8; ++q)
+                        if (e0 + q < (int64_t)mend * r) tr8[q] = t[e0 + q];
+                }
             }
         }
     };
-    if (mstart < mend) fetch(mstart);
+    if (mstart < mend) fetch(mstart, 0);
     for (int r0 = mstart; r0 < mend; r0 += 64) {
-        __syncthreads();  // previous slab fully consumed
+        f32x4 ua = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * 256 + tid;
-            *reinterpret_cast<u32x4*>(Xs + (c / 16) * WG_LD + (c % 16) * 8) = xr[q];
-        }
-        if (tid < tvecs) *reinterpret_cast<bf16x8*>(Ts + tid * 8) = tr8;
-        __syncthreads();
-        if (r0 + 64 < mend) fetch(r0 + 64);  // next slab's loads fly under this slab's MFMAs
-        // this wave: output columns [wv*32, wv*32+32) of the tile, all 64 rows of the slab
+        for (int cc = 0; cc < CT; ++cc) {
+            if (cc >= nct) break;
+            __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 b = zero8();
-            if (j < r) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) b[i] = Ts[(ks * 16 + 8 * (i >> 2) + 4 * h + (i & 3)) * r + j];
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 256 + tid;
+                *reinterpret_cast<u32x4*>(Xs + (c / 16) * WG_LD + (c % 16) * 8) = xr[q];
             }
-            bf16x8 a = tr_frag(Xs, WG_LD, ks * 16, wv * 32, lane);
-            acc = mfma32(a, b, acc);
-        }
-        if (with_u) {
-            // u_part[column tile][row][rank]: wave wv takes slab rows 16 wv .. + 15 (the MFMA's n), all 128 columns (k);
-            // D[m = 4 (lane >> 4) + i][n = lane & 15]: a lane holds four consecutive rank entries of one token row
-            f32x4 ua = {0.f, 0.f, 0.f, 0.f};
+            if (cc == 0 && tid < tvecs) *reinterpret_cast<bf16x8*>(Ts + tid * 8) = tr8;
+            __syncthreads();
+            // the next tile's loads fly under this tile's MFMAs
+            if (cc + 1 < nct) fetch(r0, cc + 1);
+            else if (r0 + 64 < mend) fetch(r0 + 64, 0);
+            // this wave: output columns [wv*32, wv*32+32) of the tile, all 64 rows of the slab
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(Xs + (wv * 16 + (lane & 15)) * WG_LD + ks * 32 + 8 * (lane >> 4));
-                ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(upf[ks], xb, ua, 0, 0, 0);
+                bf16x8 b = zero8();
+                if (j < r) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[i] = Ts[(ks * 16 + 8 * (i >> 2) + 4 * h + (i & 3)) * r + j];
+                }
+                bf16x8 a = tr_frag(Xs, WG_LD, ks * 16, wv * 32, lane);
+                acc[cc] = mfma32(a, b, acc[cc]);
             }
+            if (with_u) {
+                // wave wv takes slab rows 16 wv .. + 15 (the MFMA's n), the tile's 128 columns (k);
+                // D[m = 4 (lane >> 4) + i][n = lane & 15]: a lane holds four consecutive rank entries of one token row
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 xb = *reinterpret_cast<const bf16x8*>(Xs + (wv * 16 + (lane & 15)) * WG_LD + ks * 32 + 8 * (lane >> 4));
+                    ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(upf[cc][ks], xb, ua, 0, 0, 0);
+                }
+            }
+        }
+        if (with_u) {  // u_part[strip][row][rank]
             const int row = r0 + wv * 16 + (lane & 15), jq = 4 * (lane >> 4);
             if (row < mend && jq < r) *reinterpret_cast<f32x4*>(u_part + ((int64_t)blockIdx.x * M + row) * r + jq) = ua;
         }
     }
     if (j < r) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = k0 + wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (k < K) p.part[((int64_t)mb * K + k) * r + j] = acc[i];
-        }
+        for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = k0 + cc * WG_COLS + wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (cc < nct && k < K) p.part[((int64_t)mb * K + k) * r + j] = acc[cc][i];
+            }
     }
 }
 
@@ -648,7 +670,8 @@ static int wgrad_launch(const void* x, const void* u, const void* dy, const void
     VFT_CHECK_ARG(which >= 1 && which <= 3, "%s: which = %d", name, which);
     VFT_CHECK_ARG((up_t == nullptr) == (u_part == nullptr) && (up_t == nullptr || (which == 2 && r % 4 == 0 && r <= 16 && (((uintptr_t)up_t | (uintptr_t)u_part) & 15) == 0)),
                   "%s: the u partial sums need the dy-only launch, a rank padded to 4 / 8 / 16 and 16-byte aligned up_t / u_part", name);
-    const int rpb = wgrad_rows_per_block(M, (which & 1) ? K : 0, (which & 2) ? N : 0);
+    constexpr int UCT = 4;  // column tiles per workgroup of the dy pass that also produces u (see the kernel)
+    const int rpb = wgrad_rows_per_block(M, (which & 1) ? K : 0, (which & 2) ? (u_part ? (N + UCT - 1) / UCT : N) : 0);
     const int nmb = (M + rpb - 1) / rpb;
     const size_t need = (size_t)nmb * ((which & 1 ? (size_t)K : 0) + (which & 2 ? (size_t)N : 0)) * (size_t)r * sizeof(float);
     VFT_CHECK_ARG(ws_bytes >= need, "%s: workspace too small (%zu < %zu bytes)", name, ws_bytes, need);
@@ -662,9 +685,13 @@ static int wgrad_launch(const void* x, const void* u, const void* dy, const void
     }
     const size_t lds = 64 * WG_LD * 2 + 64 * (size_t)r * 2;
     const int kmax = which == 3 ? (K > N ? K : N) : (which == 1 ? K : N);
-    hipLaunchKernelGGL(lora_wgrad_partial_kernel, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, which == 3 ? 2 : 1), dim3(256), lds,
-                       (hipStream_t)stream, pa, pb, M, r, rpb, (ReduceDesc*)defer_slot, nmb, scale, accumulate, which == 2 ? 1 : 0,
-                       (const bf16_t*)up_t, u_part);
+    if (u_part != nullptr)
+        hipLaunchKernelGGL(lora_wgrad_partial_kernel<UCT>, dim3((kmax + UCT * WG_COLS - 1) / (UCT * WG_COLS), nmb, 1), dim3(256), lds,
+                           (hipStream_t)stream, pa, pb, M, r, rpb, (ReduceDesc*)defer_slot, nmb, scale, accumulate, 1, (const bf16_t*)up_t, u_part);
+    else
+        hipLaunchKernelGGL(lora_wgrad_partial_kernel<1>, dim3((kmax + WG_COLS - 1) / WG_COLS, nmb, which == 3 ? 2 : 1), dim3(256), lds,
+                           (hipStream_t)stream, pa, pb, M, r, rpb, (ReduceDesc*)defer_slot, nmb, scale, accumulate, which == 2 ? 1 : 0,
+                           (const bf16_t*)nullptr, (float*)nullptr);
     VFT_CHECK_LAUNCH("vft_lora_wgrad2(partial)");
     if (defer_slot != nullptr) return 0;  // the reduction is queued: vft_lora_wgrad_reduce_many runs it
     const int64_t ne = (int64_t)kmax * r;
@@ -729,10 +756,11 @@ extern "C" int vft_lora_wgrad2g_defer(const void* x, const void* u, const void* 
 //                   then an ordered sum.  Replaces vft_lora_down(dy, lora_up^T) + half of vft_lora_wgrad2g.
 // vft_lora_bwd_x:   d(lora_down) partial sums (problem "u^T x" only) — the other half.
 // table / slot: as vft_lora_wgrad2g_defer (one descriptor per call), or table == nullptr for an immediate reduction.
-extern "C" int64_t vft_lora_u_part_floats(int M, int N, int r) { return (int64_t)((N + WG_COLS - 1) / WG_COLS) * M * r; }
-// bytes of partial sums of ONE of the two problems (cols = N for vft_lora_bwd_dy, K for vft_lora_bwd_x)
-extern "C" size_t vft_lora_bwd_workspace(int M, int cols, int r) {
-    const int rpb = wgrad_rows_per_block(M, cols, 0);
+static int u_strips(int N) { return (N + 4 * WG_COLS - 1) / (4 * WG_COLS); }  // 512-column strips of the dy pass
+extern "C" int64_t vft_lora_u_part_floats(int M, int N, int r) { return (int64_t)u_strips(N) * M * r; }
+// bytes of partial sums of ONE of the two problems: cols = N, with_u = 1 for vft_lora_bwd_dy; cols = K, with_u = 0 for vft_lora_bwd_x
+extern "C" size_t vft_lora_bwd_workspace(int M, int cols, int r, int with_u) {
+    const int rpb = wgrad_rows_per_block(M, with_u ? (cols + 3) / 4 : cols, 0);
     return (size_t)((M + rpb - 1) / rpb) * (size_t)cols * (size_t)r * sizeof(float);
 }
 
@@ -747,7 +775,7 @@ extern "C" int vft_lora_bwd_dy(const void* dy, const void* t, const void* up_t, 
         return 1;
     const int64_t n4 = (int64_t)M * r / 4;
     hipLaunchKernelGGL(lora_u_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u_part,
-                       (bf16_t*)u_out, (int64_t)M, r, (N + WG_COLS - 1) / WG_COLS, scale_u);
+                       (bf16_t*)u_out, (int64_t)M, r, u_strips(N), scale_u);
     VFT_CHECK_LAUNCH("vft_lora_bwd_dy(u reduce)");
     return 0;
 }

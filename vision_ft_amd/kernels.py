@@ -857,7 +857,7 @@ def _lora_bwd_rank(x2, dy2, t, Bt, params, r: int, rp: int, s: float):
     du = (ctypes.c_void_p * 3)(*[t_[1].data_ptr() for t_ in targets])
     u = torch.empty((M, rp), dtype=torch.bfloat16, device=x2.device)
     u_part = torch.empty(int(lib.vft_lora_u_part_floats(M, N, rp)), dtype=torch.float32, device=x2.device)
-    nb_dy, nb_x = int(lib.vft_lora_bwd_workspace(M, N, rp)), int(lib.vft_lora_bwd_workspace(M, K, rp))
+    nb_dy, nb_x = int(lib.vft_lora_bwd_workspace(M, N, rp, 1)), int(lib.vft_lora_bwd_workspace(M, K, rp, 0))
     q = table = None
     ws_dy = ws_x = None
     if inplace and DEFER_WGRAD_REDUCE:
