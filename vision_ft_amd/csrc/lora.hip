@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void lora_down32_kernel(const bf16_t* __restri
 // blockIdx.z selects the problem (0: X=x,T=u -> dA ; 1: X=dy,T=t -> dB).
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_COLS = 128, WG_LD = WG_COLS + 8;
+constexpr int UCT = 1;  // column tiles per workgroup of the dy pass that also produces u (see lora_wgrad_partial_kernel)
 
 // rows of X each workgroup reduces: large enough that few partials are written, small enough that
 // (row blocks x column tiles x 2 problems) still fills 256 CUs a few times over
@@ -320,9 +321,11 @@ struct ReduceDesc {
 // over the strips in order by lora_u_reduce_kernel.  That replaces vft_lora_down(dy): one full read of dy per adapted
 // layer and backward pass (the FeedForward up-projection's dy is 1 GB at the SDXL headline shape) for a partial-sum round
 // trip of 6 % of it at rank 4.
-// CT = column tiles (of 128) one workgroup walks per row slab: 1 (the form of rounds 1-4), or 4 for the pass over dy that also
-// produces u — its partial sums are then per 512-column STRIP: a quarter of the u_part round trip (at the padded rank 16 of a
-// fused q|k|v the per-tile form cost half of what the removed pass over dy had cost).
+// CT = column tiles (of 128) one workgroup walks per row slab.  1 everywhere.  CT = 4 for the pass over dy that also produces
+// u (partial sums per 512-column strip: a quarter of the u_part round trip) was built and measured in round 5: SLOWER — the
+// grid shrinks fourfold against a 256-row floor on the row blocks (288 workgroups at M 24 576, N 1 280) and the pass loses
+// more to the thinner stream than the smaller round trip returns (SDXL-LoRA step 462.7 ms against 454.6 with CT = 1 and
+// 459.2 with the two-kernel form of round 4, one box).  UCT below selects it.
 template <int CT>
 __global__ __launch_bounds__(256) void lora_wgrad_partial_kernel(WgradProblem p0, WgradProblem p1, int M, int r,
                                                                  int rows_per_block, ReduceDesc* slot, int nmb_total,
@@ -670,7 +673,6 @@ static int wgrad_launch(const void* x, const void* u, const void* dy, const void
     VFT_CHECK_ARG(which >= 1 && which <= 3, "%s: which = %d", name, which);
     VFT_CHECK_ARG((up_t == nullptr) == (u_part == nullptr) && (up_t == nullptr || (which == 2 && r % 4 == 0 && r <= 16 && (((uintptr_t)up_t | (uintptr_t)u_part) & 15) == 0)),
                   "%s: the u partial sums need the dy-only launch, a rank padded to 4 / 8 / 16 and 16-byte aligned up_t / u_part", name);
-    constexpr int UCT = 4;  // column tiles per workgroup of the dy pass that also produces u (see the kernel)
     const int rpb = wgrad_rows_per_block(M, (which & 1) ? K : 0, (which & 2) ? (u_part ? (N + UCT - 1) / UCT : N) : 0);
     const int nmb = (M + rpb - 1) / rpb;
     const size_t need = (size_t)nmb * ((which & 1 ? (size_t)K : 0) + (which & 2 ? (size_t)N : 0)) * (size_t)r * sizeof(float);
@@ -756,11 +758,11 @@ extern "C" int vft_lora_wgrad2g_defer(const void* x, const void* u, const void* 
 //                   then an ordered sum.  Replaces vft_lora_down(dy, lora_up^T) + half of vft_lora_wgrad2g.
 // vft_lora_bwd_x:   d(lora_down) partial sums (problem "u^T x" only) — the other half.
 // table / slot: as vft_lora_wgrad2g_defer (one descriptor per call), or table == nullptr for an immediate reduction.
-static int u_strips(int N) { return (N + 4 * WG_COLS - 1) / (4 * WG_COLS); }  // 512-column strips of the dy pass
+static int u_strips(int N) { return (N + UCT * WG_COLS - 1) / (UCT * WG_COLS); }  // partial-sum planes of u
 extern "C" int64_t vft_lora_u_part_floats(int M, int N, int r) { return (int64_t)u_strips(N) * M * r; }
 // bytes of partial sums of ONE of the two problems: cols = N, with_u = 1 for vft_lora_bwd_dy; cols = K, with_u = 0 for vft_lora_bwd_x
 extern "C" size_t vft_lora_bwd_workspace(int M, int cols, int r, int with_u) {
-    const int rpb = wgrad_rows_per_block(M, with_u ? (cols + 3) / 4 : cols, 0);
+    const int rpb = wgrad_rows_per_block(M, with_u ? (cols + UCT - 1) / UCT : cols, 0);
     return (size_t)((M + rpb - 1) / rpb) * (size_t)cols * (size_t)r * sizeof(float);
 }
 
