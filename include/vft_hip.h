@@ -138,7 +138,7 @@ int vft_lora_wgrad_reduce_many(const void* table, int n, int64_t max_elements, v
  *   vft_lora_bwd_dy: the pass over dy[M,N] yields BOTH d(lora_up) = scale_w * dy^T t (partial sums + reduction exactly as
  *                    vft_lora_wgrad2g / _defer do for that half; table == NULL: reduced at once) AND
  *                    u_out[M,r] (bf16) = scale_u * dy . lora_up — the operand the data gradient's rank extension needs
- *                    (vft_linear_fwd on the transposed weight, ext_x = u) — through per-512-column-strip partial sums in u_part
+ *                    (vft_linear_fwd on the transposed weight, ext_x = u) — through per-column-tile partial sums in u_part
  *                    (vft_lora_u_part_floats(M, N, r) floats) added in tile order (deterministic).  up_t = lora_up^T (r,N),
  *                    r the padded rank (4 / 8 / 16).  Replaces vft_lora_down(dy, up_t): one full read of dy per layer.
  *   vft_lora_bwd_x:  d(lora_down) = scale_w * u^T x, the other half of vft_lora_wgrad2g.

@@ -317,8 +317,8 @@ struct ReduceDesc {
 
 // Round 5 — the data gradient's low-rank activations u = s * dy * B ride in the pass over dy (`up_t` / `u_part` non-null, the
 // problem with X = dy): the workgroup's 64 x 128 slab of dy is in LDS anyway, so four v_mfma_f32_16x16x32_bf16 per wave and
-// slab give its contribution to u for those 64 rows from these 128 columns — u_part[512-column strip][row][rank] (fp32), summed
-// over the strips in order by lora_u_reduce_kernel.  That replaces vft_lora_down(dy): one full read of dy per adapted
+// slab give its contribution to u for those 64 rows from these 128 columns — u_part[column tile][row][rank] (fp32), summed
+// over the column tiles in order by lora_u_reduce_kernel.  That replaces vft_lora_down(dy): one full read of dy per adapted
 // layer and backward pass (the FeedForward up-projection's dy is 1 GB at the SDXL headline shape) for a partial-sum round
 // trip of 6 % of it at rank 4.
 // CT = column tiles (of 128) one workgroup walks per row slab.  1 everywhere.  CT = 4 for the pass over dy that also produces
