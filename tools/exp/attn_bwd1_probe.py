@@ -25,7 +25,7 @@ for (B, H, S, D) in ((24, 10, 4096, 64), (24, 20, 1024, 64)):
     do = bf(B, S, H, D).permute(0, 2, 1, 3)
     times = {}
     for i in range(9):
-        for dbg in (0, 1, 2, 8, 9, 11):
+        for dbg in tuple(int(v) for v in os.environ.get("VFT_PROBE_SET", "0,1,2,8,9,11").split(",")):
             os.environ["VFT_ATTN_DEBUG"] = str(dbg)
             o = kernels.flash_attention(q, k, v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

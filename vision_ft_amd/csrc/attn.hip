@@ -2508,7 +2508,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
     const float sc = p.scale * kLog2e;
     const int nqt = (p.Sq + BQ - 1) / BQ;
     const int niter = G * nqt;
-    const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s, ks_s = (int)p.sk.s;
+    const int qs_s = (int)p.sq.s, dos_s = (int)p.sdo.s, ks_s = (int)p.sk.s, sdq_s = (int)p.sdq.s;
     const int64_t plane = (int64_t)p.B * p.Hq * nqt * (BQ * D);   // floats per scratch plane
     float* const scr = p.split_ws + (int64_t)split * plane;
 
@@ -2610,7 +2610,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         // offset is past the descriptor (zeros); in the range's first key block there is nothing to read (empty descriptor)
         float* const pair_scr = scr + tile_id_of(0) * (BQ * D);
         const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, (first || (dbg & 1)) ? 0 : niter * (BQ * D * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wpl = __builtin_amdgcn_make_buffer_rsrc((void*)pair_scr, 0, (dbg & 1) ? 0 : niter * (BQ * D * 4), 0x00020000);
         const int old_lane = ((w & 3) * 1024 + (2 * kh) * 256 + lane * 4) * 4;
+        // dQ of the query head under the cursor (last key block of an unsliced range only)
+        __amdgpu_buffer_rsrc_t hrdq = rpl;
+        auto dq_rsrc = [&](int gq) {
+            const bool live = gq < G;
+            hrdq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dq + b * p.sdq.b + (hkv * G + (live ? gq : 0)) * p.sdq.h), 0,
+                                                     live ? (int)(((int64_t)(p.Sq - 1) * p.sdq.s + D) * 2) : 0, 0x00020000);
+        };
+        if (final_store) dq_rsrc(0);
+        const int dq_lane = ((qtw * 32 + r) * sdq_s + dtw * 32 + 16 * kh + 4 * h) * 2;
         auto old_dma = [&](int it) {
             const int voff = old_lane + it * (BQ * D * 4);
             dma16_nt(rpl, smem + OLD + w * 2048, voff);
@@ -2774,22 +2784,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 sum0 = f32x4{acc[8], acc[9], acc[10], acc[11]} + p0 + o0;
                 sum1 = f32x4{acc[12], acc[13], acc[14], acc[15]} + p1 + o1;
             }
-            const int gq = cg, t = ct;
-            if (++ct == nqt) ct = 0, ++cg;
+            // stores through buffer descriptors (a per-lane 32-bit offset that never changes + a scalar tile offset; rows past
+            // the tensor's end dropped by the range check): no 64-bit per-lane pointers to keep or rebuild
             if (final_store) {
-                const int q = t * BQ + qtw * 32 + r;
-                if (q < p.Sq) {
-                    bf16_t* dst = p.dq + b * p.sdq.b + (hkv * G + gq) * p.sdq.h + (int64_t)q * p.sdq.s + dtw * 32 + 16 * kh + 4 * h;
-                    const float s_ = p.scale;
-                    store4(dst, sum0[0] * s_, sum0[1] * s_, sum0[2] * s_, sum0[3] * s_);
-                    store4(dst + 8, sum1[0] * s_, sum1[1] * s_, sum1[2] * s_, sum1[3] * s_);
+                const float s_ = p.scale;
+                bf16x4 v0, v1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v0[i] = (bf16_t)(sum0[i] * s_);
+                    v1[i] = (bf16_t)(sum1[i] * s_);
+                }
+                const int soff = ct * (BQ * sdq_s * 2);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v0), hrdq, dq_lane, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v1), hrdq, dq_lane + 16, soff, 0);
+                if (++ct == nqt) {
+                    ct = 0;
+                    ++cg;
+                    dq_rsrc(cg);
                 }
             } else {
-                float* s0 = pair_scr + (int64_t)it * (BQ * D) + (w & 3) * 1024 + (2 * kh) * 256 + lane * 4;
-                if (!(dbg & 1)) {
-                    *reinterpret_cast<f32x4*>(s0) = sum0;
-                    *reinterpret_cast<f32x4*>(s0 + 256) = sum1;
-                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum0), wpl, old_lane, it * (BQ * D * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum1), wpl, old_lane + 1024, it * (BQ * D * 4), 0);
             }
             old_dma(it + 1);  // (the reads of this tile's copy above are complete: their values went into the sums)
             buf = buf == NB - 1 ? 0 : buf + 1;
