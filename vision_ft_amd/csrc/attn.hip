@@ -2468,10 +2468,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(AttnParams p) {
 // to an eighth as well): ~0.9 ms of memory stalls (12.4 GB per launch at 3.2 TB/s, planes + Q / dO of 240 workgroups that
 // share nothing), and a 2.7 ms core in which the eight waves run M1 -> softmax -> M2 in lock step between two workgroup
 // barriers per tile (both waves of a SIMD want the matrix pipe, then both the vector ALU): DESIGN §10.
+#ifdef VFT_ATTN_STAMP  // diagnostic build only (tools/exp/attn_bwd1_stamps.py): cycles per segment of the tile loop, summed per wave of workgroup 0
+__device__ unsigned long long g_bwd1_stamps[8][16];
+#define BWD1_STAMP(k)                                                                  \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        unsigned long long t_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        seg[k] += (unsigned)(t_ - tprev);                                              \
+        tprev = t_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+extern "C" int vft_attn_probe_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd1_stamps), sizeof(g_bwd1_stamps));
+}
+#else
+#define BWD1_STAMP(k)
+#endif
 template <int D>
 __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
+#ifdef VFT_ATTN_STAMP
+    unsigned seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+#endif
 #ifdef VFT_ATTN_PROBE
     const int dbg = p.dbg;
+    // (bits 16 / 32: static issue priority for waves 4-7 / for the odd waves — measured: no effect)
+    if ((dbg & 16) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((dbg & 32) && ((threadIdx.x >> 6) & 1)) __builtin_amdgcn_s_setprio(1);
 #else
     constexpr int dbg = 0;
 #endif
@@ -2673,6 +2697,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                     }
                 }
             };
+#ifdef VFT_ATTN_STAMP
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             read_rows(0);
             init_acc(0);
 #pragma unroll
@@ -2691,6 +2722,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                     tc[st] = trfrag(Qq + (st & 1) * 16 * RB, st >> 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                BWD1_STAMP(0 + 3 * qt);  // R (first sub-tile) + M1 issue + T issue (+ the stamp's wait for T)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {  // V
                     const float pv = __builtin_amdgcn_exp2f(S[i] * sc);
@@ -2722,6 +2754,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                 }
                 if (qt + 1 < QT) read_rows(qt + 1);  // the next sub-tile's row fragments fly during this one's dV / dK MFMAs
                 __builtin_amdgcn_sched_barrier(0);
+                BWD1_STAMP(1 + 3 * qt);  // wait for S / dP + V + W
                 // M2: dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
 #pragma unroll
                 for (int st = 0; st < 2 * DT; ++st) {
@@ -2729,10 +2762,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                     dK[st >> 1] = mfma32(tc[st], dSf[st & 1], dK[st >> 1]);
                 }
                 if (qt + 1 < QT) init_acc(qt + 1);  // (issued behind the MFMAs: S / dP are free again, the reads overlap their execution)
+                BWD1_STAMP(2 + 3 * qt);  // M2 issue
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // B1: the dS image is complete; tile it-1's buffer is free
+            BWD1_STAMP(6);  // B1
             stage(it + 2, buf == 0 ? NB - 1 : buf - 1);
+            BWD1_STAMP(7);  // staging DMAs issued
             // ---- phase 2: dQ^T block of this wave over its key half, operand fragments four steps ahead --------------
             f32x16 acc;
 #pragma unroll
@@ -2758,6 +2794,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
                     acc = mfma32(a_, b_, acc);
                 }
             }
+            BWD1_STAMP(8);  // dQ product: transposed reads + 8 MFMAs issued
             // swap halves with the partner wave (w ^ 4, the same block over the other key half): keep quads 2 kh, 2 kh + 1
             f32x4* xo = xch + (w * 2) * 64 + lane;
             if (kh == 0) {
@@ -2772,6 +2809,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
             // three DMAs just issued may still fly
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3) : "memory");
             __builtin_amdgcn_s_barrier();  // B2
+            BWD1_STAMP(9);  // exchange stores (wait for the dQ MFMAs) + vmcnt + B2
             const f32x4* xi = xch + ((w ^ 4) * 2) * 64 + lane;
             const f32x4* oi = reinterpret_cast<const f32x4*>(smem + OLD + w * 2048) + lane;
             const f32x4 p0 = xi[0], p1 = xi[64];
@@ -2808,6 +2846,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
             }
             old_dma(it + 1);  // (the reads of this tile's copy above are complete: their values went into the sums)
             buf = buf == NB - 1 ? 0 : buf + 1;
+            BWD1_STAMP(10);  // read-modify-write of the running dQ + next tile's plane DMA
         }
         // ---- dK, dV of this key block ----
         if (kmem) {
@@ -2827,6 +2866,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnParams p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+#ifdef VFT_ATTN_STAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 12; ++k) g_bwd1_stamps[w][k] = seg[k];
+#endif
 }
 
 // dQ = scale * (sum over the key-range slices' scratch planes, in slice order) -> bf16; one thread = one float4 of the
