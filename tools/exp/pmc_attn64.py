@@ -15,7 +15,7 @@ shapes = [(24, 10, 4096, 64), (24, 20, 1024, 64)] if len(sys.argv) < 2 else [tup
 for B, H, S, D in shapes:
     q, k, v = (bf(B, S, H, D).permute(0, 2, 1, 3).requires_grad_(True) for _ in range(3))
     do = bf(B, S, H, D).permute(0, 2, 1, 3)
-    for var in (0, 3):
+    for var in tuple(int(x) for x in os.environ.get("VFT_PMC_VARIANTS", "0,3").split(",")):
         _C.lib().vft_attn_variant(var)
         for _ in range(2):
             kernels.flash_attention(q, k, v).backward(do)

@@ -17,7 +17,7 @@ for (name, grid), c in sorted(acc.items()):
     if "SQ_BUSY_CU_CYCLES" in a and "SQ_VALU_MFMA_BUSY_CYCLES" in a:
         line += f"  mfma_busy/cu_busy {a['SQ_VALU_MFMA_BUSY_CYCLES'] / a['SQ_BUSY_CU_CYCLES'] / 4:.3f}"  # 4 SIMDs per CU
     if "SQ_WAVE_CYCLES" in a:
-        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        for k in sorted(k for k in a if k.startswith(("SQ_WAIT", "SQ_ACTIVE_INST", "SQ_INST_CYCLES"))):
             if k in a:
                 line += f"  {k[3:]} {a[k] / a['SQ_WAVE_CYCLES']:.3f}"
     if "SQ_LDS_IDX_ACTIVE" in a and "SQ_LDS_BANK_CONFLICT" in a:
