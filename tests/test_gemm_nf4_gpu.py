@@ -30,6 +30,11 @@ def test_nf4_odd_reduction_dimension_falls_back_to_a_dense_copy(gpu):
     dx = kernels._nf4_gemm(dy, q, None, True)  # K = out_features = 96
     wb = wd.to(torch.bfloat16).float()
     assert rel_err(dx.cpu(), dy.cpu().float() @ wb) < 5e-3
+    # ... and keeps the rank extension and the residual of the fused call
+    ex, ew, res = _bf(g, 50, 4).to(gpu), _bf(g, 128, 4).to(gpu), _bf(g, 50, 128).to(gpu)
+    dx2 = kernels._nf4_gemm(dy, q, None, True, ext_x=ex, ext_w=ew, residual=res)
+    want = dy.cpu().float() @ wb + ex.cpu().float() @ ew.cpu().float().t() + res.cpu().float()
+    assert rel_err(dx2.cpu(), want) < 5e-3
 
 
 @pytest.mark.parametrize("double_quant", [False, True])

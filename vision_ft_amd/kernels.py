@@ -2269,7 +2269,11 @@ def _nf4_gemm(a2: torch.Tensor, q: NF4State, bias, transpose_w: bool, ext_x=None
         # a reduction dimension the dequantising GEMM does not take (none in the three models): dense copy + library GEMM
         w = nf4_dequantize(q)
         out = a2 @ (w if transpose_w else w.t())
-        return out if bias is None else out + bias
+        if bias is not None:
+            out = out + bias
+        if ext_x is not None:
+            out = out + ext_x @ ext_w.t()
+        return out if residual is None else out + residual.reshape(out.shape)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=a2.device)
     r = ext_x.shape[1] if ext_x is not None else 0
     ws, ws_bytes = None, 0
